@@ -1,0 +1,175 @@
+"""Micro-benchmarks of the gfx950 kernels at Llama-3-8B serving shapes.
+
+Prints one JSON line per case: achieved HBM bandwidth for the bandwidth-bound ops, TFLOP/s for the
+prefill attention.  Timing: hip events around ``iters`` back-to-back launches after warm-up, on
+random data (cdna guide §5.4 rule 25).
+
+    python benchmarks/bench_kernels.py [--quick] [--only decode]
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dli_amd import ops  # noqa: E402
+from dli_amd.ops.kv_layout import allocate_kv_cache  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def report(name, seconds, bytes_=None, flops=None, **kw):
+    row = {"kernel": name, "us": round(seconds * 1e6, 2)}
+    if bytes_:
+        row["GB/s"] = round(bytes_ / seconds / 1e9, 1)
+    if flops:
+        row["TFLOP/s"] = round(flops / seconds / 1e12, 2)
+    row.update(kw)
+    print(json.dumps(row), flush=True)
+
+
+def bench_norm(T, H=4096):
+    x = torch.randn(T, H, device=DEV).bfloat16()
+    r = torch.randn(T, H, device=DEV).bfloat16()
+    w = torch.randn(H, device=DEV).bfloat16()
+    report("rms_norm", timeit(lambda: ops.rms_norm(x, w, 1e-5)), bytes_=2 * T * H * 2, T=T, H=H)
+    report("fused_add_rms_norm", timeit(lambda: ops.fused_add_rms_norm(x, r, w, 1e-5)), bytes_=4 * T * H * 2, T=T, H=H)
+
+
+def bench_silu(T, I=14336):
+    x = torch.randn(T, 2 * I, device=DEV).bfloat16()
+    report("silu_and_mul", timeit(lambda: ops.silu_and_mul(x)), bytes_=3 * T * I * 2, T=T, I=I)
+
+
+def bench_rope(T, Hq=32, Hkv=8):
+    qkv = torch.randn(T, (Hq + 2 * Hkv) * 128, device=DEV).bfloat16()
+    nblocks = (T + 31) // 32 + 1
+    kc, vc = allocate_kv_cache(1, nblocks, Hkv, 128, torch.bfloat16, DEV)[0]
+    pos = torch.arange(T, dtype=torch.int32, device=DEV) % 4096
+    slots = torch.arange(T, dtype=torch.int32, device=DEV)
+    cs = ops.ref.build_cos_sin_cache(4096, 128, 5e5, DEV)
+    t = timeit(lambda: ops.rope_and_cache(qkv, pos, cs, slots, kc, vc, Hq, Hkv, 128))
+    report("rope_and_cache", t, bytes_=T * ((Hq + Hkv) * 2 + Hkv * 3) * 128 * 2, T=T)
+
+
+def _decode_case(B, ctx, Hq, Hkv, kv_dtype, splits=None):
+    nb_seq = (ctx + 31) // 32
+    nblocks = B * nb_seq + 1
+    kc, vc = allocate_kv_cache(1, nblocks, Hkv, 128, kv_dtype, DEV)[0]
+    if kv_dtype == torch.bfloat16:
+        kc.normal_()
+        vc.normal_()
+    else:
+        kc.view(torch.uint8).random_(0, 120)
+        vc.view(torch.uint8).random_(0, 120)
+    bt = torch.randperm(nblocks - 1, device=DEV).to(torch.int32).reshape(B, nb_seq)
+    sl = torch.full((B,), ctx, dtype=torch.int32, device=DEV)
+    qsl = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * 128, device=DEV).bfloat16()
+    if splits is None:
+        splits = ops.choose_decode_splits(B, Hkv, ctx)
+    ws = torch.empty(B * Hq * splits * 130, dtype=torch.float32, device=DEV)
+    meta = ops.AttnMetadata(B, 0, B, None, None, bt, sl, qsl, decode_splits=splits, decode_workspace=ws)
+    out = torch.empty(B, Hq * 128, device=DEV, dtype=torch.bfloat16)
+    scale = 1 / math.sqrt(128)
+    fn = lambda: ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, scale, out=out)
+    kv_bytes = B * nb_seq * 32 * Hkv * 128 * 2 * kc.element_size()
+    return fn, kv_bytes, splits
+
+
+def bench_decode(quick):
+    cases = [(256, 700), (64, 700), (8, 2048), (1, 2048), (512, 1024)]
+    if quick:
+        cases = cases[:2]
+    for B, ctx in cases:
+        for kv_dtype in (torch.bfloat16, torch.float8_e4m3fn):
+            fn, nbytes, splits = _decode_case(B, ctx, 32, 8, kv_dtype)
+            report("paged_attention_decode", timeit(fn), bytes_=nbytes, B=B, ctx=ctx, splits=splits,
+                   kv=str(kv_dtype).split(".")[-1])
+    fn, nbytes, splits = _decode_case(256, 1024, 8, 1, torch.bfloat16)       # 70B TP=8 shard
+    report("paged_attention_decode", timeit(fn), bytes_=nbytes, B=256, ctx=1024, splits=splits, shape="70b-tp8")
+
+
+def bench_prefill(quick):
+    Hq, Hkv = 32, 8
+    for nseq, L in ([(4, 1024)] if quick else [(4, 1024), (16, 512), (2, 2048), (1, 4096)]):
+        nb_seq = (L + 31) // 32
+        nblocks = nseq * nb_seq + 1
+        kc, vc = allocate_kv_cache(1, nblocks, Hkv, 128, torch.bfloat16, DEV)[0]
+        kc.normal_()
+        vc.normal_()
+        bt = torch.randperm(nblocks - 1, device=DEV).to(torch.int32).reshape(nseq, nb_seq)
+        sl = torch.full((nseq,), L, dtype=torch.int32, device=DEV)
+        qsl = (torch.arange(nseq + 1, device=DEV) * L).to(torch.int32)
+        T = nseq * L
+        qkv = torch.randn(T, (Hq + 2 * Hkv) * 128, device=DEV).bfloat16()
+        tq = ops.prefill_tile_tokens(Hq, Hkv)
+        ts, t0 = ops.build_prefill_tiles(np.full(nseq, L), 0, tq)
+        meta = ops.AttnMetadata(0, nseq, T, None, None, bt, sl, qsl, prefill_tile_seq=torch.from_numpy(ts).to(DEV),
+                                prefill_tile_q0=torch.from_numpy(t0).to(DEV), num_prefill_tiles=len(ts))
+        out = torch.empty(T, Hq * 128, device=DEV, dtype=torch.bfloat16)
+        scale = 1 / math.sqrt(128)
+        t = timeit(lambda: ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, scale, out=out), iters=10)
+        flops = 4 * nseq * (L * L / 2) * 128 * Hq
+        report("paged_attention_prefill", t, flops=flops, nseq=nseq, L=L)
+
+
+def bench_sampler(quick):
+    for B, V in ([(256, 128256)] if quick else [(256, 128256), (64, 128256), (256, 32000)]):
+        logits = torch.randn(B, V, device=DEV).bfloat16()
+        one = torch.ones(B, device=DEV)
+        zk = torch.zeros(B, dtype=torch.int32, device=DEV)
+        seeds = torch.arange(B, dtype=torch.int64, device=DEV)
+        steps = torch.zeros(B, dtype=torch.int64, device=DEV)
+        out = torch.empty(B, dtype=torch.int64, device=DEV)
+        report("sample(T=0.7)", timeit(lambda: ops.sample(logits, one * 0.7, one, zk, seeds, steps, out=out)),
+               bytes_=B * V * 2, B=B, V=V)
+        report("sample(greedy)", timeit(lambda: ops.sample(logits, one * 0, one, zk, seeds, steps, out=out)),
+               bytes_=B * V * 2, B=B, V=V)
+        report("sample(top_p=0.9,top_k=50)",
+               timeit(lambda: ops.sample(logits, one * 0.7, one * 0.9, zk + 50, seeds, steps, out=out)), B=B, V=V)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    ops.hip()
+    run = lambda name: not a.only or a.only in name
+    if run("norm"):
+        for T in (256, 4096):
+            bench_norm(T)
+    if run("silu"):
+        for T in (256, 4096):
+            bench_silu(T)
+    if run("rope"):
+        for T in (256, 4096):
+            bench_rope(T)
+    if run("decode"):
+        bench_decode(a.quick)
+    if run("prefill"):
+        bench_prefill(a.quick)
+    if run("sampler"):
+        bench_sampler(a.quick)
+
+
+if __name__ == "__main__":
+    main()

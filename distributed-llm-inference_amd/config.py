@@ -1,0 +1,143 @@
+"""Configuration dataclasses for the serving stack.
+
+The reference has no server-side configuration at all (its only config is the harness dict at
+`/root/reference/traffic_generator/main.py:302-313`); SURVEY.md §5.6 asks for a dataclass config
+for the new server.  Model shapes are the public ones listed in SURVEY.md §2.5.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from typing import Optional
+
+KV_BLOCK_SIZE = 32          # tokens per KV page: one MFMA k-step (16x16x32) of the P·V product
+
+
+@dataclass
+class ModelConfig:
+    name: str = "llama3-8b"
+    arch: str = "llama"                 # "llama" | "mixtral" | "opt"
+    vocab_size: int = 128256
+    hidden_size: int = 4096
+    intermediate_size: int = 14336
+    num_layers: int = 32
+    num_heads: int = 32
+    num_kv_heads: int = 8
+    head_dim: int = 128
+    max_position: int = 8192
+    rope_theta: float = 500000.0
+    rms_eps: float = 1e-5
+    # mixture of experts
+    num_experts: int = 0
+    top_k_experts: int = 0
+    # OPT specifics
+    pos_offset: int = 0                 # learned positions start at this offset (OPT: 2)
+    tie_embeddings: bool = False
+    dtype: str = "bfloat16"
+    bos_token_id: int = 1
+    eos_token_id: int = 2
+
+    @property
+    def q_per_kv(self) -> int:
+        return self.num_heads // self.num_kv_heads
+
+    def param_count(self) -> int:
+        h, i, v, l = self.hidden_size, self.intermediate_size, self.vocab_size, self.num_layers
+        attn = h * (self.num_heads + 2 * self.num_kv_heads) * self.head_dim + self.num_heads * self.head_dim * h
+        if self.arch == "opt":
+            mlp = 2 * h * i
+        else:
+            mlp = 3 * h * i * max(self.num_experts, 1)
+        emb = v * h * (1 if self.tie_embeddings else 2)
+        return l * (attn + mlp) + emb
+
+
+MODEL_PRESETS: dict[str, ModelConfig] = {
+    "llama3-8b": ModelConfig(),
+    "llama3-70b": ModelConfig(name="llama3-70b", hidden_size=8192, intermediate_size=28672, num_layers=80,
+                              num_heads=64, num_kv_heads=8),
+    "mixtral-8x7b": ModelConfig(name="mixtral-8x7b", arch="mixtral", vocab_size=32000, hidden_size=4096,
+                                intermediate_size=14336, num_layers=32, num_heads=32, num_kv_heads=8,
+                                rope_theta=1e6, max_position=32768, num_experts=8, top_k_experts=2),
+    "opt-125m": ModelConfig(name="opt-125m", arch="opt", vocab_size=50272, hidden_size=768,
+                            intermediate_size=3072, num_layers=12, num_heads=12, num_kv_heads=12,
+                            head_dim=64, max_position=2048, pos_offset=2, tie_embeddings=True,
+                            dtype="float32", bos_token_id=2, eos_token_id=2),
+    # tiny shapes for CPU tests / smoke (same code paths, seconds to run)
+    "tiny-llama": ModelConfig(name="tiny-llama", vocab_size=512, hidden_size=128, intermediate_size=256,
+                              num_layers=2, num_heads=8, num_kv_heads=2, head_dim=16, max_position=512,
+                              dtype="float32"),
+    "tiny-llama-d128": ModelConfig(name="tiny-llama-d128", vocab_size=1024, hidden_size=512,
+                                   intermediate_size=1024, num_layers=2, num_heads=4, num_kv_heads=1,
+                                   head_dim=128, max_position=4096),
+    "tiny-mixtral": ModelConfig(name="tiny-mixtral", arch="mixtral", vocab_size=512, hidden_size=128,
+                                intermediate_size=256, num_layers=2, num_heads=8, num_kv_heads=2,
+                                head_dim=16, max_position=512, num_experts=4, top_k_experts=2,
+                                dtype="float32"),
+    "tiny-opt": ModelConfig(name="tiny-opt", arch="opt", vocab_size=512, hidden_size=64,
+                            intermediate_size=128, num_layers=2, num_heads=4, num_kv_heads=4,
+                            head_dim=16, max_position=512, pos_offset=2, tie_embeddings=True,
+                            dtype="float32", bos_token_id=2, eos_token_id=2),
+}
+
+
+def get_model_config(name: str, **overrides) -> ModelConfig:
+    if name not in MODEL_PRESETS:
+        raise KeyError(f"unknown model preset {name!r}; have {sorted(MODEL_PRESETS)}")
+    return dataclasses.replace(MODEL_PRESETS[name], **overrides)
+
+
+@dataclass
+class CacheConfig:
+    block_size: int = KV_BLOCK_SIZE
+    kv_dtype: str = "auto"              # "auto" (= model dtype) | "fp8" (OCP e4m3, per-tensor scale)
+    num_blocks: Optional[int] = None    # None → size from free HBM after weights + activation peak
+    gpu_memory_utilization: float = 0.92
+    enable_prefix_caching: bool = True
+
+
+@dataclass
+class SchedulerConfig:
+    max_num_seqs: int = 512                 # concurrent sequences per step
+    max_num_batched_tokens: int = 8192      # token budget per step (decode tokens + prefill chunk)
+    max_model_len: int = 4096
+    long_prefill_chunk: int = 2048          # per-request cap on one step's prefill chunk
+    enable_chunked_prefill: bool = True
+
+
+@dataclass
+class ParallelConfig:
+    tp: int = 1
+    dp: int = 1
+    ep: int = 1                             # expert-parallel degree (MoE); ep ≤ tp, experts sharded over tp group
+    custom_all_reduce: bool = True
+    backend: str = "auto"                   # "auto" → nccl(=RCCL) on GPU, gloo on CPU
+
+
+@dataclass
+class EngineConfig:
+    model: ModelConfig = field(default_factory=ModelConfig)
+    cache: CacheConfig = field(default_factory=CacheConfig)
+    sched: SchedulerConfig = field(default_factory=SchedulerConfig)
+    parallel: ParallelConfig = field(default_factory=ParallelConfig)
+    device: str = "auto"                    # "auto" | "cuda" | "cpu"
+    seed: int = 0
+    use_hip_graphs: bool = True
+    graph_batch_sizes: tuple = (1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512)
+    weights_path: Optional[str] = None      # safetensors dir/file; None → random init
+    tokenizer_path: Optional[str] = None    # HF tokenizer.json; None → byte-level tokenizer
+
+
+@dataclass
+class SamplingParams:
+    temperature: float = 1.0
+    top_p: float = 1.0
+    top_k: int = 0                          # 0 → disabled
+    max_tokens: int = 128
+    ignore_eos: bool = False
+    seed: Optional[int] = None
+    stop_token_ids: tuple = ()
+
+    def clamp(self, max_model_len: int, prompt_len: int) -> "SamplingParams":
+        room = max(max_model_len - prompt_len, 1)
+        return dataclasses.replace(self, max_tokens=max(1, min(self.max_tokens, room)))

@@ -1,0 +1,405 @@
+// K4 / K5: paged attention for gfx950 — single-query decode (split-KV) and chunked-prefill
+// (varlen, causal, paged prefix) — on v_mfma_f32_16x16x32_bf16.
+//
+// Both kernels use the *transposed* formulation so that nothing ever moves between lanes:
+//
+//   Sᵀ[token, qcol] = K[token, :] · Qᵀ[:, qcol]      A = K page rows (tokens), B = Qᵀ
+//   Oᵀ[d, qcol]    += Vᵀ[d, token] · Pᵀ[token, qcol]  A = Vᵀ page rows (d),    B = Pᵀ
+//
+// A lane (qcol = lane & 15, g = lane >> 4) therefore owns one query column for the whole kernel: its
+// Sᵀ accumulators are 4 tokens of that column, the online-softmax state (m, l) is per lane, and the
+// exponentiated accumulators of two 16-token tiles are — after a bf16 pack — exactly the B fragment
+// of the P·V MFMA, because the V page stores its 32 tokens in that register order
+// (ops/kv_layout.py).  K and V fragments are 16-byte loads straight from the page to VGPRs: every
+// wave-level load is one contiguous 1 KiB, each byte of the cache is read once per consumer wave,
+// so decode needs no LDS staging (memory-bound GEMV-like regime).
+//
+// qcol meaning:  decode  → query head inside the GQA group (G <= 16, padded columns are zero)
+//                prefill → query token inside a 16-token tile, one (head, tile) "column group" per
+//                          accumulator set, two column groups per wave.
+//
+// KV8: pages hold OCP e4m3 (K chunks are 64 wide, see kv_layout); values are widened to bf16 in
+// registers, the per-tensor scales are folded into the softmax scale (K) and the epilogue (V).
+#include "common.h"
+#include "kernels.h"
+
+namespace dli {
+
+constexpr int HD = 128;                 // head dim
+constexpr int PAGE_ELEMS = HD * 32;     // elements per (page, kv head)
+constexpr float NEG_BIG = -1.0e30f;
+
+// 4 packed e4m3 bytes → 4 bf16 (elements 4i..4i+3 of a fragment)
+__device__ __forceinline__ void fp8x4_to_bf16(uint32_t w, bf16x8& f, int base) {
+  const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+  const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  f[base + 0] = (short)f2bf(lo[0]);
+  f[base + 1] = (short)f2bf(lo[1]);
+  f[base + 2] = (short)f2bf(hi[0]);
+  f[base + 3] = (short)f2bf(hi[1]);
+}
+
+// ---- fragment loads ------------------------------------------------------------------------------
+// K fragment for row tile rt (tokens 16rt..16rt+15) and k-step c (0..3) of lane (col, g).
+template <bool KV8>
+struct KLoader {
+  // bf16: page [4][32 tok][32]:  element offset ((c*32 + rt*16 + col)*32 + 8g)
+  // fp8 : page [2][32 tok][64]:  byte offset ((c2*32 + rt*16 + col)*64 + 16g) holds k-steps 2c2, 2c2+1
+  static __device__ __forceinline__ void load(const void* page, int col, int g, bf16x8 (&kf)[2][4]) {
+    if constexpr (!KV8) {
+      const uint16_t* p = reinterpret_cast<const uint16_t*>(page) + col * 32 + g * 8;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) kf[rt][c] = *reinterpret_cast<const bf16x8*>(p + (c * 32 + rt * 16) * 32);
+    } else {
+      const uint8_t* p = reinterpret_cast<const uint8_t*>(page) + col * 64 + g * 16;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(p + (c2 * 32 + rt * 16) * 64);
+          const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            bf16x8 f;
+            fp8x4_to_bf16(w[2 * h], f, 0);
+            fp8x4_to_bf16(w[2 * h + 1], f, 4);
+            kf[rt][2 * c2 + h] = f;
+          }
+        }
+    }
+  }
+  // Matching d index of element j of the B (Qᵀ) fragment for k-step c of lane group g.
+  static __device__ __forceinline__ int q_d0(int c, int g) {
+    if constexpr (!KV8) return 32 * c + 8 * g;
+    else return 64 * (c >> 1) + 16 * g + 8 * (c & 1);
+  }
+};
+
+// V fragment for d tile n (rows 16n..16n+15) of lane (col, g): slots 8g..8g+7 of row d = 16n + col.
+template <bool KV8>
+__device__ __forceinline__ bf16x8 load_v(const void* page, int n, int col, int g) {
+  if constexpr (!KV8) {
+    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(page) + (16 * n + col) * 32 + 8 * g);
+  } else {
+    const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(page) + (16 * n + col) * 32 + 8 * g);
+    bf16x8 f;
+    fp8x4_to_bf16(raw.x, f, 0);
+    fp8x4_to_bf16(raw.y, f, 4);
+    return f;
+  }
+}
+
+__device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing a column
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+// One 32-token page against one query-column set: Sᵀ → online softmax → Pᵀ fragment.
+// `limit`: tokens with index > limit are masked (limit = L-1 for decode, query position for prefill).
+template <bool MASK>
+__device__ __forceinline__ bf16x8 softmax_step(f32x4 (&s)[2], int tok0, int limit, float scale_log2, float& m,
+                                               float& lsum, float& alpha) {
+  float mx = m;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = s[rt][r] * scale_log2;
+      if (MASK) v = (tok0 + rt * 16 + r <= limit) ? v : NEG_BIG;
+      s[rt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = group_max(mx);
+  alpha = fast_exp2(m - mx);
+  m = mx;
+  float ps = 0.f;
+  bf16x8 pb;
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p = fast_exp2(s[rt][r] - mx);
+      if (MASK) p = (tok0 + rt * 16 + r <= limit) ? p : 0.f;
+      ps += p;
+      pb[rt * 4 + r] = (short)f2bf(p);
+    }
+  lsum = lsum * alpha + ps;
+  return pb;
+}
+
+// ==================================================================================================
+// Decode: grid (num_seqs, Hkv, num_splits), 4 waves; wave w takes pages w, w+4, … of its split.
+// ==================================================================================================
+template <bool KV8>
+__global__ __launch_bounds__(256) void paged_decode_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens, uint16_t* __restrict__ out,
+    int64_t out_stride, float* __restrict__ part_o, float* __restrict__ part_ml, int Hq, int Hkv, int num_splits,
+    float scale_log2, float v_scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int seq = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+  const int G = Hq / Hkv;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int L = seq_lens[seq];
+  const int nblk = (L + 31) >> 5;
+  const int per = (nblk + num_splits - 1) / num_splits;
+  const int b_begin = split * per;
+  const int b_end = min(nblk, b_begin + per);
+  constexpr int ESZ = KV8 ? 1 : 2;
+
+  bf16x8 qf[4];
+  {
+    const bool ok = col < G;
+    const uint16_t* qp = q + (int64_t)seq * q_stride + (kvh * G + (ok ? col : 0)) * HD;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + KLoader<KV8>::q_d0(c, g));
+      qf[c] = ok ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  f32x4 o[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = NEG_BIG, lsum = 0.f;
+
+  const int* bt = block_tables + (int64_t)seq * max_blocks;
+  const char* kc = reinterpret_cast<const char*>(k_cache);
+  const char* vc = reinterpret_cast<const char*>(v_cache);
+
+  for (int b = b_begin + wave; b < b_end; b += 4) {
+    const int64_t page = ((int64_t)bt[b] * Hkv + kvh) * (PAGE_ELEMS * ESZ);
+    bf16x8 kf[2][4];
+    KLoader<KV8>::load(kc + page, col, g, kf);
+    bf16x8 vf[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) vf[n] = load_v<KV8>(vc + page, n, col, g);
+
+    f32x4 s[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      s[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[rt] = mfma16(kf[rt][c], qf[c], s[rt]);
+    }
+    float alpha;
+    bf16x8 pb;
+    const int tok0 = b * 32 + 4 * g;
+    if (b == nblk - 1) pb = softmax_step<true>(s, tok0, L - 1, scale_log2, m, lsum, alpha);
+    else pb = softmax_step<false>(s, tok0, L - 1, scale_log2, m, lsum, alpha);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      o[n] *= alpha;
+      o[n] = mfma16(vf[n], pb, o[n]);
+    }
+  }
+  lsum = group_sum(lsum);
+
+  // ---- merge the 4 waves through LDS: [wave][G][128] fp32 + [wave][G] (m, l)
+  float* sm_o = smem;
+  float* sm_m = smem + 4 * G * HD;
+  float* sm_l = sm_m + 4 * G;
+  if (col < G) {
+    float* dst = sm_o + (wave * G + col) * HD + 4 * g;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = o[n];
+    if (g == 0) { sm_m[wave * G + col] = m; sm_l[wave * G + col] = lsum; }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < G * HD; idx += 256) {
+    const int head = idx >> 7, d = idx & 127;
+    float M = NEG_BIG;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, sm_m[w * G + head]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = fast_exp2(sm_m[w * G + head] - M);
+      num += f * sm_o[(w * G + head) * HD + d];
+      den += f * sm_l[w * G + head];
+    }
+    const int qh = kvh * G + head;
+    if (num_splits == 1) {
+      const float r = den > 0.f ? v_scale / den : 0.f;
+      out[(int64_t)seq * out_stride + qh * HD + d] = f2bf(num * r);
+    } else {
+      const int64_t slot = ((int64_t)seq * Hq + qh) * num_splits + split;
+      part_o[slot * HD + d] = num;
+      if (d == 0) { part_ml[slot * 2] = M; part_ml[slot * 2 + 1] = den; }
+    }
+  }
+}
+
+// grid (num_seqs, Hq), 128 threads: combine the split partials.
+__global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                            uint16_t* __restrict__ out, int64_t out_stride, int Hq,
+                                                            int num_splits, float v_scale) {
+  const int seq = blockIdx.x, qh = blockIdx.y, d = threadIdx.x;
+  const int64_t base = ((int64_t)seq * Hq + qh) * num_splits;
+  float M = NEG_BIG;
+  for (int s = 0; s < num_splits; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < num_splits; ++s) {
+    const float f = fast_exp2(part_ml[(base + s) * 2] - M);
+    num += f * part_o[(base + s) * HD + d];
+    den += f * part_ml[(base + s) * 2 + 1];
+  }
+  const float r = den > 0.f ? v_scale / den : 0.f;
+  out[(int64_t)seq * out_stride + qh * HD + d] = f2bf(num * r);
+}
+
+// ==================================================================================================
+// Prefill: grid (num_tiles, Hkv), 4 waves.  A tile is TQ = 16·(8/G) consecutive query tokens of one
+// sequence; its 8 column groups (head, 16-token sub-tile) are spread two per wave.  All K/V — paged
+// prefix and the chunk itself — come from the cache (rope_and_cache has already written the chunk).
+// ==================================================================================================
+template <bool KV8>
+__global__ __launch_bounds__(256) void paged_prefill_kernel(
+    const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
+    const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens,
+    const int* __restrict__ query_start_loc, const int* __restrict__ tile_seq, const int* __restrict__ tile_q0,
+    uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, float scale_log2, float v_scale) {
+  const int kvh = blockIdx.y;
+  const int G = Hq / Hkv;                      // 1, 2, 4 or 8 (checked on the host)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 15, g = lane >> 4;
+  const int seq = tile_seq[blockIdx.x], q0 = tile_q0[blockIdx.x];
+  const int qs = query_start_loc[seq];
+  const int n_new = query_start_loc[seq + 1] - qs;
+  const int L = seq_lens[seq];
+  const int ctx = L - n_new;
+  constexpr int ESZ = KV8 ? 1 : 2;
+
+  int head[2], qtok[2], qpos[2];
+  bool valid[2];
+  int first_tok = 1 << 30, last_pos = -1;      // wave-uniform bounds over both column groups
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int cg = 2 * wave + i;
+    head[i] = cg % G;
+    const int t0 = q0 + (cg / G) * 16;
+    qtok[i] = t0 + col;
+    valid[i] = qtok[i] < n_new;
+    qpos[i] = ctx + min(qtok[i], n_new - 1);
+    if (t0 < n_new) {
+      first_tok = min(first_tok, ctx + t0);
+      last_pos = max(last_pos, ctx + min(t0 + 15, n_new - 1));
+    }
+  }
+  if (last_pos < 0) return;                    // both sub-tiles are past the end of the chunk
+  const int nblk = (last_pos >> 5) + 1;
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const uint16_t* qp = q + (int64_t)(qs + min(qtok[i], n_new - 1)) * q_stride + (kvh * G + head[i]) * HD;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[i][c] = *reinterpret_cast<const bf16x8*>(qp + KLoader<KV8>::q_d0(c, g));
+  }
+
+  f32x4 o[2][8];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) o[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
+
+  const int* bt = block_tables + (int64_t)seq * max_blocks;
+  const char* kc = reinterpret_cast<const char*>(k_cache);
+  const char* vc = reinterpret_cast<const char*>(v_cache);
+
+  for (int b = 0; b < nblk; ++b) {
+    const int64_t page = ((int64_t)bt[b] * Hkv + kvh) * (PAGE_ELEMS * ESZ);
+    bf16x8 kf[2][4];
+    KLoader<KV8>::load(kc + page, col, g, kf);
+    const bool need_mask = b * 32 + 31 > first_tok;   // some query of this wave sits before the page end
+    bf16x8 pb[2];
+    float alpha[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      f32x4 s[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        s[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[rt] = mfma16(kf[rt][c], qf[i][c], s[rt]);
+      }
+      const int tok0 = b * 32 + 4 * g;
+      if (need_mask) pb[i] = softmax_step<true>(s, tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
+      else pb[i] = softmax_step<false>(s, tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const bf16x8 vf = load_v<KV8>(vc + page, n, col, g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        o[i][n] *= alpha[i];
+        o[i][n] = mfma16(vf, pb[i], o[i][n]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float l = group_sum(lsum[i]);
+    if (!valid[i]) continue;
+    const float r = l > 0.f ? v_scale / l : 0.f;
+    uint16_t* op = out + (int64_t)(qs + qtok[i]) * out_stride + (kvh * G + head[i]) * HD + 4 * g;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      bf16x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (short)f2bf(o[i][n][e] * r);
+      *reinterpret_cast<bf16x4*>(op + 16 * n) = w;
+    }
+  }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------
+void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                         const int* block_tables, int max_blocks, const int* seq_lens, void* out, int64_t out_stride,
+                         float* part_o, float* part_ml, int num_seqs, int Hq, int Hkv, int num_splits, float scale,
+                         bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
+  if (num_seqs == 0) return;
+  const int G = Hq / Hkv;
+  const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
+  const size_t lds = (size_t)(4 * G * HD + 8 * G) * sizeof(float);
+  dim3 grid(num_seqs, Hkv, num_splits);
+  if (kv_fp8)
+    hipLaunchKernelGGL(paged_decode_kernel<true>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
+                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
+                       num_splits, scale_log2, v_scale);
+  else
+    hipLaunchKernelGGL(paged_decode_kernel<false>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
+                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
+                       num_splits, scale_log2, 1.f);
+  if (num_splits > 1)
+    hipLaunchKernelGGL(decode_reduce_kernel, dim3(num_seqs, Hq), dim3(128), 0, stream, part_o, part_ml, (uint16_t*)out,
+                       out_stride, Hq, num_splits, kv_fp8 ? v_scale : 1.f);
+}
+
+void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                          const int* block_tables, int max_blocks, const int* seq_lens, const int* query_start_loc,
+                          const int* tile_seq, const int* tile_q0, int num_tiles, void* out, int64_t out_stride, int Hq,
+                          int Hkv, float scale, bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
+  if (num_tiles == 0) return;
+  const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
+  dim3 grid(num_tiles, Hkv);
+  if (kv_fp8)
+    hipLaunchKernelGGL(paged_prefill_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
+                       v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
+                       out_stride, Hq, Hkv, scale_log2, v_scale);
+  else
+    hipLaunchKernelGGL(paged_prefill_kernel<false>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
+                       v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
+                       out_stride, Hq, Hkv, scale_log2, 1.f);
+}
+
+}  // namespace dli

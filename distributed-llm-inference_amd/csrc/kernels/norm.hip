@@ -1,0 +1,107 @@
+// K1: RMSNorm and fused residual-add + RMSNorm.
+//
+// One 256-thread workgroup per token row; 16-byte (8 x bf16) vector loads; the row stays in
+// registers between the sum-of-squares pass and the scale pass (H <= 8192 → <= 4 vectors per
+// thread), so HBM/L2 sees every byte once.  Wave reduction by cross-lane shuffles, 4 partials
+// through LDS.  Bandwidth kernel: no MFMA, no LDS tiling.
+#include "common.h"
+#include "kernels.h"
+
+namespace dli {
+
+constexpr int NT = 256;
+constexpr int MAXV = 4;   // register-cached vectors per thread → H <= 256*8*4 = 8192 in one pass
+
+template <bool ADD_RESIDUAL>
+__global__ __launch_bounds__(NT) void rms_norm_kernel(uint16_t* out, const uint16_t* x,   // may alias (in-place form)
+                                                      uint16_t* residual, const uint16_t* __restrict__ w,
+                                                      float eps, int H, int64_t x_stride, int64_t out_stride) {
+  __shared__ float red[NT / 64];
+  const int64_t row = blockIdx.x;
+  const uint16_t* xr = x + row * x_stride;
+  uint16_t* rr = ADD_RESIDUAL ? residual + row * (int64_t)H : nullptr;
+  uint16_t* orow = out + row * out_stride;
+  const int nvec = H >> 3;
+
+  float vals[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = threadIdx.x + i * NT;
+    if (v < nvec) {
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+      if (ADD_RESIDUAL) {
+        bf16x8 r = *reinterpret_cast<const bf16x8*>(rr + v * 8);
+        bf16x8 s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = bf2f((uint16_t)a[j]) + bf2f((uint16_t)r[j]);
+          vals[i][j] = f;
+          s[j] = (short)f2bf(f);
+          ss += f * f;
+        }
+        *reinterpret_cast<bf16x8*>(rr + v * 8) = s;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = bf2f((uint16_t)a[j]);
+          vals[i][j] = f;
+          ss += f * f;
+        }
+      }
+    }
+  }
+  // rows wider than the register cache: extra vectors are re-read in the second pass
+  for (int v = threadIdx.x + MAXV * NT; v < nvec; v += NT) {
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+    bf16x8 s;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = bf2f((uint16_t)a[j]);
+      if (ADD_RESIDUAL) f += bf2f(rr[v * 8 + j]);
+      s[j] = (short)f2bf(f);
+      ss += f * f;
+    }
+    if (ADD_RESIDUAL) *reinterpret_cast<bf16x8*>(rr + v * 8) = s;
+  }
+
+  const float tot = block_sum<NT>(ss, red);
+  const float inv = rsqrtf(tot / (float)H + eps);
+
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = threadIdx.x + i * NT;
+    if (v < nvec) {
+      bf16x8 g = *reinterpret_cast<const bf16x8*>(w + v * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(vals[i][j] * inv * bf2f((uint16_t)g[j]));
+      *reinterpret_cast<bf16x8*>(orow + v * 8) = o;
+    }
+  }
+  for (int v = threadIdx.x + MAXV * NT; v < nvec; v += NT) {
+    const uint16_t* src = ADD_RESIDUAL ? rr : xr;   // (residual already holds the rounded sum)
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(src + v * 8);
+    bf16x8 g = *reinterpret_cast<const bf16x8*>(w + v * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(bf2f((uint16_t)a[j]) * inv * bf2f((uint16_t)g[j]));
+    *reinterpret_cast<bf16x8*>(orow + v * 8) = o;
+  }
+}
+
+void launch_rms_norm(void* out, const void* x, const void* w, float eps, int rows, int H, int64_t x_stride,
+                     int64_t out_stride, hipStream_t stream) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(rms_norm_kernel<false>, dim3(rows), dim3(NT), 0, stream, (uint16_t*)out, (const uint16_t*)x,
+                     (uint16_t*)nullptr, (const uint16_t*)w, eps, H, x_stride, out_stride);
+}
+
+void launch_fused_add_rms_norm(void* x, void* residual, const void* w, float eps, int rows, int H, int64_t x_stride,
+                               hipStream_t stream) {
+  if (rows == 0) return;
+  hipLaunchKernelGGL(rms_norm_kernel<true>, dim3(rows), dim3(NT), 0, stream, (uint16_t*)x, (const uint16_t*)x,
+                     (uint16_t*)residual, (const uint16_t*)w, eps, H, x_stride, x_stride);
+}
+
+}  // namespace dli

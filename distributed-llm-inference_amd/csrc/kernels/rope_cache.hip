@@ -1,0 +1,125 @@
+// K2: NeoX rotate-half RoPE on q and k fused with the paged-KV write.
+//
+// One 256-thread workgroup per token.  Work items are 8-element (16-byte) chunks: a q/k item owns
+// the pair (x[d0:d0+8], x[d0+64:d0+72]) of one head, so both halves of the rotation are produced by
+// the same thread; cos/sin come from a host-built fp32 table (no device trig).  Rotated k goes back
+// into the qkv buffer (the prefill kernel reads everything from the cache, but the in-place result
+// keeps the op's semantics testable) and into the K page as one 16-byte store per chunk; v goes into
+// the transposed, slot-permuted V page (layout: ops/kv_layout.py).
+//
+// KV8 = true stores the cache as OCP e4m3 with per-tensor scales (value / scale, saturating).
+#include "common.h"
+#include "kernels.h"
+
+namespace dli {
+
+constexpr int D = 128;
+
+__device__ __forceinline__ int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
+
+template <bool KV8>
+__global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv, int64_t row_stride,
+                                                         const int* __restrict__ positions,
+                                                         const float* __restrict__ cos_sin,  // [max_pos, D] or null
+                                                         const int* __restrict__ slot_mapping,
+                                                         void* __restrict__ k_cache_, void* __restrict__ v_cache_,
+                                                         int Hq, int Hkv, float k_inv_scale, float v_inv_scale) {
+  const int64_t t = blockIdx.x;
+  uint16_t* row = qkv + t * row_stride;
+  const int slot = slot_mapping[t];
+  const int pos = positions[t];
+  const int blk = slot >> 5, tok = slot & 31;
+  const int n_rot = (Hq + Hkv) * 8;
+  const int n_items = n_rot + Hkv * 16;
+
+  for (int it = threadIdx.x; it < n_items; it += blockDim.x) {
+    if (it < n_rot) {
+      const int head = it >> 3, j = it & 7;
+      uint16_t* p = row + head * D + j * 8;
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+      bf16x8 b = *reinterpret_cast<const bf16x8*>(p + 64);
+      float fa[8], fb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { fa[e] = bf2f((uint16_t)a[e]); fb[e] = bf2f((uint16_t)b[e]); }
+      if (cos_sin != nullptr) {
+        const float* cs = cos_sin + (int64_t)pos * D + j * 8;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64), s1 = *reinterpret_cast<const f32x4*>(cs + 68);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float c = e < 4 ? c0[e] : c1[e - 4], s = e < 4 ? s0[e] : s1[e - 4];
+          const float x1 = fa[e], x2 = fb[e];
+          fa[e] = x1 * c - x2 * s;
+          fb[e] = x2 * c + x1 * s;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = (short)f2bf(fa[e]); b[e] = (short)f2bf(fb[e]); }
+        *reinterpret_cast<bf16x8*>(p) = a;
+        *reinterpret_cast<bf16x8*>(p + 64) = b;
+      }
+      if (head >= Hq && slot >= 0) {             // k head → K page
+        const int h = head - Hq;
+        const int64_t page = (int64_t)blk * Hkv + h;
+        if (!KV8) {
+          uint16_t* kc = reinterpret_cast<uint16_t*>(k_cache_) + page * (D * 32);
+          const int d0 = j * 8, d1 = 64 + j * 8;   // chunk c = d/32, offset d%32
+          *reinterpret_cast<bf16x8*>(kc + ((d0 >> 5) * 32 + tok) * 32 + (d0 & 31)) = a;
+          *reinterpret_cast<bf16x8*>(kc + ((d1 >> 5) * 32 + tok) * 32 + (d1 & 31)) = b;
+        } else {
+          uint8_t* kc = reinterpret_cast<uint8_t*>(k_cache_) + page * (D * 32);
+          uint64_t pa = 0, pb = 0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pa |= (uint64_t)f_to_fp8(bf2f((uint16_t)a[e]) * k_inv_scale) << (8 * e);
+            pb |= (uint64_t)f_to_fp8(bf2f((uint16_t)b[e]) * k_inv_scale) << (8 * e);
+          }
+          // chunk c = d/64: first half is chunk 0, second half chunk 1
+          *reinterpret_cast<uint64_t*>(kc + (0 * 32 + tok) * 64 + j * 8) = pa;
+          *reinterpret_cast<uint64_t*>(kc + (1 * 32 + tok) * 64 + j * 8) = pb;
+        }
+      }
+    } else if (slot >= 0) {                      // v chunk → transposed V page
+      const int vi = it - n_rot;
+      const int h = vi >> 4, d0 = (vi & 15) * 8;
+      bf16x8 a = *reinterpret_cast<const bf16x8*>(row + (Hq + Hkv + h) * D + d0);
+      const int64_t page = (int64_t)blk * Hkv + h;
+      const int s = v_slot(tok);
+      if (!KV8) {
+        uint16_t* vc = reinterpret_cast<uint16_t*>(v_cache_) + page * (D * 32) + d0 * 32 + s;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vc[e * 32] = (uint16_t)a[e];
+      } else {
+        uint8_t* vc = reinterpret_cast<uint8_t*>(v_cache_) + page * (D * 32) + d0 * 32 + s;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vc[e * 32] = f_to_fp8(bf2f((uint16_t)a[e]) * v_inv_scale);
+      }
+    }
+  }
+}
+
+void launch_rope_and_cache(void* qkv, int64_t row_stride, const int* positions, const float* cos_sin,
+                           const int* slot_mapping, void* k_cache, void* v_cache, int T, int Hq, int Hkv,
+                           bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
+  if (T == 0) return;
+  if (kv_fp8)
+    hipLaunchKernelGGL(rope_cache_kernel<true>, dim3(T), dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
+                       cos_sin, slot_mapping, k_cache, v_cache, Hq, Hkv, 1.f / k_scale, 1.f / v_scale);
+  else
+    hipLaunchKernelGGL(rope_cache_kernel<false>, dim3(T), dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
+                       cos_sin, slot_mapping, k_cache, v_cache, Hq, Hkv, 1.f, 1.f);
+}
+
+// K9 helper: device-side page copy for copy-on-write (pairs = [n, 2] int32: src, dst page ids).
+__global__ void copy_pages_kernel(uint8_t* __restrict__ cache, const int* __restrict__ pairs, int64_t page_bytes) {
+  const int64_t src = pairs[2 * blockIdx.x], dst = pairs[2 * blockIdx.x + 1];
+  const uint4* s = reinterpret_cast<const uint4*>(cache + src * page_bytes);
+  uint4* d = reinterpret_cast<uint4*>(cache + dst * page_bytes);
+  for (int64_t i = threadIdx.x; i < page_bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+
+void launch_copy_pages(void* cache, const int* pairs, int n_pairs, int64_t page_bytes, hipStream_t stream) {
+  if (n_pairs == 0) return;
+  hipLaunchKernelGGL(copy_pages_kernel, dim3(n_pairs), dim3(256), 0, stream, (uint8_t*)cache, pairs, page_bytes);
+}
+
+}  // namespace dli

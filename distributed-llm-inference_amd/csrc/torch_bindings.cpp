@@ -1,0 +1,180 @@
+// torch.ops.dli.* — argument checking + stream plumbing around the HIP launchers in kernels/.
+// Every op launches on the *current* HIP stream, so the ops are capturable into hipGraphs
+// (torch.cuda.graph) without any host synchronisation (cdna guide §6 G9).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "kernels/kernels.h"
+
+namespace {
+
+using at::Tensor;
+
+hipStream_t cur_stream(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check_bf16_rows(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda(), name, " must be a GPU tensor");
+  TORCH_CHECK(t.scalar_type() == at::kBFloat16, name, " must be bfloat16");
+  TORCH_CHECK(t.dim() == 2 && t.stride(1) == 1, name, " must be 2-D with contiguous rows");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(t.data_ptr()) % 16 == 0 && t.stride(0) % 8 == 0, name, " rows must be 16-byte aligned");
+}
+void check_i32(const Tensor& t, const char* name) {
+  TORCH_CHECK(t.is_cuda() && t.scalar_type() == at::kInt && t.is_contiguous(), name, " must be a contiguous int32 GPU tensor");
+}
+bool is_fp8(const Tensor& t) { return t.scalar_type() == at::kFloat8_e4m3fn; }
+
+Tensor rms_norm(const Tensor& x, const Tensor& weight, double eps) {
+  check_bf16_rows(x, "x");
+  const int64_t H = x.size(1);
+  TORCH_CHECK(H % 8 == 0 && weight.numel() == H && weight.scalar_type() == at::kBFloat16 && weight.is_contiguous());
+  Tensor out = at::empty({x.size(0), H}, x.options());
+  dli::launch_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), (float)eps, (int)x.size(0), (int)H, x.stride(0), H,
+                       cur_stream(x));
+  return out;
+}
+
+void fused_add_rms_norm(Tensor x, Tensor residual, const Tensor& weight, double eps) {
+  check_bf16_rows(x, "x");
+  check_bf16_rows(residual, "residual");
+  const int64_t H = x.size(1);
+  TORCH_CHECK(residual.is_contiguous() && residual.sizes() == x.sizes(), "residual must be contiguous and shaped like x");
+  TORCH_CHECK(H % 8 == 0 && weight.numel() == H && weight.scalar_type() == at::kBFloat16 && weight.is_contiguous());
+  dli::launch_fused_add_rms_norm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), (float)eps, (int)x.size(0), (int)H,
+                                 x.stride(0), cur_stream(x));
+}
+
+Tensor silu_and_mul(const Tensor& x) {
+  check_bf16_rows(x, "x");
+  const int64_t I = x.size(1) / 2;
+  TORCH_CHECK(x.size(1) % 16 == 0, "silu_and_mul: row width must be a multiple of 16");
+  Tensor out = at::empty({x.size(0), I}, x.options());
+  dli::launch_silu_and_mul(out.data_ptr(), x.data_ptr(), (int)x.size(0), (int)I, x.stride(0), cur_stream(x));
+  return out;
+}
+
+void check_cache(const Tensor& k_cache, const Tensor& v_cache, int64_t Hkv) {
+  TORCH_CHECK(k_cache.is_cuda() && v_cache.is_cuda() && k_cache.is_contiguous() && v_cache.is_contiguous());
+  TORCH_CHECK(k_cache.scalar_type() == v_cache.scalar_type() && (k_cache.scalar_type() == at::kBFloat16 || is_fp8(k_cache)),
+              "KV cache must be bfloat16 or float8_e4m3fn");
+  TORCH_CHECK(v_cache.dim() == 4 && v_cache.size(1) == Hkv && v_cache.size(2) == 128 && v_cache.size(3) == 32,
+              "V cache must be [blocks, Hkv, 128, 32]");
+  TORCH_CHECK(k_cache.dim() == 5 && k_cache.size(0) == v_cache.size(0) && k_cache.size(1) == Hkv && k_cache.size(3) == 32 &&
+                  k_cache.size(2) * k_cache.size(4) == 128 && k_cache.size(4) * k_cache.element_size() == 64,
+              "K cache must be [blocks, Hkv, 128/CH, 32, CH] with 64-byte chunks");
+}
+
+void rope_and_cache(Tensor qkv, const Tensor& positions, const c10::optional<Tensor>& cos_sin, const Tensor& slot_mapping,
+                    Tensor k_cache, Tensor v_cache, int64_t Hq, int64_t Hkv, double k_scale, double v_scale) {
+  check_bf16_rows(qkv, "qkv");
+  check_i32(positions, "positions");
+  check_i32(slot_mapping, "slot_mapping");
+  check_cache(k_cache, v_cache, Hkv);
+  const int64_t T = qkv.size(0);
+  TORCH_CHECK(qkv.size(1) == (Hq + 2 * Hkv) * 128, "qkv row must be (Hq + 2 Hkv) * 128 wide");
+  TORCH_CHECK(positions.numel() >= T && slot_mapping.numel() >= T);
+  const float* cs = nullptr;
+  if (cos_sin.has_value()) {
+    TORCH_CHECK(cos_sin->is_cuda() && cos_sin->scalar_type() == at::kFloat && cos_sin->is_contiguous() && cos_sin->size(1) == 128);
+    cs = cos_sin->data_ptr<float>();
+  }
+  dli::launch_rope_and_cache(qkv.data_ptr(), qkv.stride(0), positions.data_ptr<int>(), cs, slot_mapping.data_ptr<int>(),
+                             k_cache.data_ptr(), v_cache.data_ptr(), (int)T, (int)Hq, (int)Hkv, is_fp8(k_cache), (float)k_scale,
+                             (float)v_scale, cur_stream(qkv));
+}
+
+void copy_pages(Tensor cache, const Tensor& pairs) {
+  check_i32(pairs, "pairs");
+  TORCH_CHECK(cache.is_cuda() && cache.is_contiguous() && pairs.dim() == 2 && pairs.size(1) == 2);
+  const int64_t page_bytes = cache.numel() / cache.size(0) * cache.element_size();
+  TORCH_CHECK(page_bytes % 16 == 0);
+  dli::launch_copy_pages(cache.data_ptr(), pairs.data_ptr<int>(), (int)pairs.size(0), page_bytes, cur_stream(cache));
+}
+
+// q: [T, Hq*128] view (row stride arbitrary); the first num_seqs rows are the decode queries.
+void paged_attention_decode(Tensor out, const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& block_tables,
+                            const Tensor& seq_lens, int64_t num_seqs, int64_t Hq, int64_t Hkv, double scale, int64_t num_splits,
+                            const c10::optional<Tensor>& workspace, double k_scale, double v_scale) {
+  check_bf16_rows(q, "q");
+  check_bf16_rows(out, "out");
+  check_i32(block_tables, "block_tables");
+  check_i32(seq_lens, "seq_lens");
+  check_cache(k_cache, v_cache, Hkv);
+  TORCH_CHECK(Hq % Hkv == 0 && Hq / Hkv <= 16, "decode kernel supports up to 16 query heads per KV head");
+  TORCH_CHECK(q.size(0) >= num_seqs && out.size(0) >= num_seqs && q.size(1) == Hq * 128 && out.size(1) == Hq * 128);
+  TORCH_CHECK(block_tables.dim() == 2 && block_tables.size(0) >= num_seqs && seq_lens.numel() >= num_seqs);
+  TORCH_CHECK(num_splits >= 1 && num_splits <= 64);
+  float* part_o = nullptr;
+  float* part_ml = nullptr;
+  if (num_splits > 1) {
+    TORCH_CHECK(workspace.has_value() && workspace->is_cuda() && workspace->scalar_type() == at::kFloat && workspace->is_contiguous());
+    const int64_t need = num_seqs * Hq * num_splits * (128 + 2);
+    TORCH_CHECK(workspace->numel() >= need, "decode workspace too small: need ", need, " floats");
+    part_o = workspace->data_ptr<float>();
+    part_ml = part_o + num_seqs * Hq * num_splits * 128;
+  }
+  dli::launch_paged_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr<int>(),
+                           (int)block_tables.size(1), seq_lens.data_ptr<int>(), out.data_ptr(), out.stride(0), part_o, part_ml,
+                           (int)num_seqs, (int)Hq, (int)Hkv, (int)num_splits, (float)scale, is_fp8(k_cache), (float)k_scale,
+                           (float)v_scale, cur_stream(q));
+}
+
+void paged_attention_prefill(Tensor out, const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& block_tables,
+                             const Tensor& seq_lens, const Tensor& query_start_loc, const Tensor& tile_seq, const Tensor& tile_q0,
+                             int64_t num_tiles, int64_t Hq, int64_t Hkv, double scale, double k_scale, double v_scale) {
+  check_bf16_rows(q, "q");
+  check_bf16_rows(out, "out");
+  check_i32(block_tables, "block_tables");
+  check_i32(seq_lens, "seq_lens");
+  check_i32(query_start_loc, "query_start_loc");
+  check_i32(tile_seq, "tile_seq");
+  check_i32(tile_q0, "tile_q0");
+  check_cache(k_cache, v_cache, Hkv);
+  const int64_t G = Hq / Hkv;
+  TORCH_CHECK(Hq % Hkv == 0 && (G == 1 || G == 2 || G == 4 || G == 8), "prefill kernel supports 1, 2, 4 or 8 query heads per KV head");
+  TORCH_CHECK(q.size(1) == Hq * 128 && out.size(1) == Hq * 128 && out.size(0) == q.size(0));
+  TORCH_CHECK(tile_seq.numel() >= num_tiles && tile_q0.numel() >= num_tiles && block_tables.dim() == 2);
+  dli::launch_paged_prefill(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr<int>(),
+                            (int)block_tables.size(1), seq_lens.data_ptr<int>(), query_start_loc.data_ptr<int>(),
+                            tile_seq.data_ptr<int>(), tile_q0.data_ptr<int>(), (int)num_tiles, out.data_ptr(), out.stride(0),
+                            (int)Hq, (int)Hkv, (float)scale, is_fp8(k_cache), (float)k_scale, (float)v_scale, cur_stream(q));
+}
+
+void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const Tensor& top_p, const Tensor& top_k,
+            const Tensor& seeds, const Tensor& steps, const c10::optional<Tensor>& noise) {
+  TORCH_CHECK(logits.is_cuda() && logits.dim() == 2 && logits.stride(1) == 1);
+  TORCH_CHECK(logits.scalar_type() == at::kBFloat16 || logits.scalar_type() == at::kFloat, "logits must be bf16 or fp32");
+  const int64_t B = logits.size(0), V = logits.size(1);
+  TORCH_CHECK(out.is_cuda() && out.scalar_type() == at::kLong && out.is_contiguous() && out.numel() >= B);
+  TORCH_CHECK(temperature.scalar_type() == at::kFloat && top_p.scalar_type() == at::kFloat && top_k.scalar_type() == at::kInt &&
+              seeds.scalar_type() == at::kLong && steps.scalar_type() == at::kLong);
+  TORCH_CHECK(temperature.numel() >= B && top_p.numel() >= B && top_k.numel() >= B && seeds.numel() >= B && steps.numel() >= B);
+  TORCH_CHECK(temperature.is_cuda() && top_p.is_cuda() && top_k.is_cuda() && seeds.is_cuda() && steps.is_cuda());
+  const float* nz = nullptr;
+  if (noise.has_value()) {
+    TORCH_CHECK(noise->is_cuda() && noise->scalar_type() == at::kFloat && noise->is_contiguous() && noise->numel() == B * V);
+    nz = noise->data_ptr<float>();
+  }
+  dli::launch_sample(logits.data_ptr(), logits.scalar_type() == at::kFloat, logits.stride(0), (int)B, (int)V,
+                     temperature.data_ptr<float>(), top_p.data_ptr<float>(), top_k.data_ptr<int>(), seeds.data_ptr<int64_t>(),
+                     steps.data_ptr<int64_t>(), nz, out.data_ptr<int64_t>(), cur_stream(logits));
+}
+
+}  // namespace
+
+TORCH_LIBRARY(dli, m) {
+  m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
+  m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
+  m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
+  m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
+        "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale) -> ()", &rope_and_cache);
+  m.def("copy_pages(Tensor(a!) cache, Tensor pairs) -> ()", &copy_pages);
+  m.def("paged_attention_decode(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, Tensor seq_lens, "
+        "int num_seqs, int num_heads, int num_kv_heads, float scale, int num_splits, Tensor? workspace, float k_scale, "
+        "float v_scale) -> ()", &paged_attention_decode);
+  m.def("paged_attention_prefill(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, Tensor seq_lens, "
+        "Tensor query_start_loc, Tensor tile_seq, Tensor tile_q0, int num_tiles, int num_heads, int num_kv_heads, float scale, "
+        "float k_scale, float v_scale) -> ()", &paged_attention_prefill);
+  m.def("sample(Tensor(a!) out, Tensor logits, Tensor temperature, Tensor top_p, Tensor top_k, Tensor seeds, Tensor steps, "
+        "Tensor? noise) -> ()", &sample);
+}

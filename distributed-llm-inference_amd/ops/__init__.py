@@ -1,0 +1,194 @@
+"""Hot ops of the serving stack (SURVEY.md §2.5 K1–K8).
+
+GPU tensors go to the hand-written gfx950 kernels in ``csrc/kernels`` through ``torch.ops.dli``
+(built in-tree into ``ops/_C.so`` by ``dli_amd.build``); CPU tensors go to the fp32 torch references
+in ``reference.py``.  There is no silent GPU fallback: a missing extension or an unsupported shape on
+a GPU tensor raises.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import reference as ref
+from .kv_layout import allocate_kv_cache, bytes_per_block, kv_cache_shapes  # noqa: F401
+
+_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C.so")
+_lib = None
+
+
+def hip():
+    """The ``torch.ops.dli`` namespace; loads ``_C.so`` on first use and fails loudly without it."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise RuntimeError(f"HIP extension {_SO} is missing: run `python -m dli_amd.build` "
+                               "(hipcc --offload-arch=gfx950) before using GPU tensors")
+        torch.ops.load_library(_SO)
+        _lib = torch.ops.dli
+    return _lib
+
+
+def hip_loaded() -> bool:
+    return _lib is not None
+
+
+def _gpu_kernel_ok(x: torch.Tensor) -> bool:
+    if not x.is_cuda:
+        return False
+    if x.dtype != torch.bfloat16:
+        raise TypeError(f"the gfx950 kernels take bfloat16 activations, got {x.dtype}")
+    return True
+
+
+# ------------------------------------------------------------------------------------ metadata
+@dataclass
+class AttnMetadata:
+    """Per-step attention inputs.  Sequences are ordered decodes first (one query token each, rows
+    ``0 … num_decode-1`` of the flattened batch), then prefill chunks."""
+    num_decode: int
+    num_prefill: int
+    num_tokens: int
+    positions: torch.Tensor            # [T] int32
+    slot_mapping: torch.Tensor         # [T] int32 (-1 = padding)
+    block_tables: torch.Tensor         # [B, max_blocks] int32
+    seq_lens: torch.Tensor             # [B] int32, context length *including* this step's tokens
+    query_start_loc: torch.Tensor      # [B+1] int32
+    max_seq_len: int = 0
+    decode_splits: int = 1
+    decode_workspace: Optional[torch.Tensor] = None
+    # prefill work list: one entry per TQ-token tile
+    prefill_tile_seq: Optional[torch.Tensor] = None
+    prefill_tile_q0: Optional[torch.Tensor] = None
+    num_prefill_tiles: int = 0
+
+
+def prefill_tile_tokens(num_heads: int, num_kv_heads: int) -> int:
+    g = num_heads // num_kv_heads
+    return 16 * max(8 // g, 1)
+
+
+def build_prefill_tiles(query_lens: np.ndarray, first_seq: int, tile_tokens: int):
+    """Host-side work list of the prefill kernel: (sequence index, first query offset) per tile."""
+    seqs, q0s = [], []
+    for i, n in enumerate(query_lens):
+        nt = (int(n) + tile_tokens - 1) // tile_tokens
+        seqs.append(np.full(nt, first_seq + i, dtype=np.int32))
+        q0s.append(np.arange(nt, dtype=np.int32) * tile_tokens)
+    if not seqs:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32)
+    return np.concatenate(seqs), np.concatenate(q0s)
+
+
+def choose_decode_splits(num_seqs: int, num_kv_heads: int, max_seq_len: int, num_cus: int = 256) -> int:
+    """Split the KV range when (sequences × KV heads) alone cannot fill the chip."""
+    groups = max(num_seqs * num_kv_heads, 1)
+    pages = max((max_seq_len + 31) // 32, 1)
+    want = (2 * num_cus + groups - 1) // groups          # aim for ≥ 2 workgroups per CU
+    return int(max(1, min(want, (pages + 3) // 4, 16)))   # keep ≥ 4 pages (one per wave) per split
+
+
+# ------------------------------------------------------------------------------------ ops
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    if _gpu_kernel_ok(x):
+        return hip().rms_norm(x, weight, eps)
+    return ref.rms_norm_ref(x, weight, eps)
+
+
+def fused_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> None:
+    """In place: ``residual += x``; ``x = rmsnorm(residual) * weight``."""
+    if _gpu_kernel_ok(x):
+        hip().fused_add_rms_norm(x, residual, weight, eps)
+    else:
+        ref.fused_add_rms_norm_ref(x, residual, weight, eps)
+
+
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    if _gpu_kernel_ok(x):
+        return hip().silu_and_mul(x)
+    return ref.silu_and_mul_ref(x)
+
+
+def rope_and_cache(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: Optional[torch.Tensor],
+                   slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                   num_heads: int, num_kv_heads: int, head_dim: int,
+                   k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+    if _gpu_kernel_ok(qkv):
+        if head_dim != 128:
+            raise ValueError("the gfx950 rope/cache kernel is specialised for head_dim 128")
+        hip().rope_and_cache(qkv, positions, cos_sin, slot_mapping, k_cache, v_cache, num_heads, num_kv_heads,
+                             k_scale, v_scale)
+    else:
+        ref.rope_and_cache_ref(qkv, positions, cos_sin, slot_mapping, k_cache, v_cache, num_heads, num_kv_heads,
+                               head_dim, k_scale, v_scale)
+
+
+def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, meta: AttnMetadata,
+                    num_heads: int, num_kv_heads: int, head_dim: int, scale: float,
+                    k_scale: float = 1.0, v_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention of this step's tokens over the paged cache (which already holds their K/V).
+    ``qkv [T, (Hq+2Hkv)·D]`` — only the q columns are read.  Returns ``[T, Hq·D]``."""
+    T = qkv.shape[0]
+    q = qkv[:, :num_heads * head_dim]
+    if _gpu_kernel_ok(qkv):
+        if head_dim != 128:
+            raise ValueError("the gfx950 attention kernels are specialised for head_dim 128")
+        if out is None:
+            out = torch.empty(T, num_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+        lib = hip()
+        if meta.num_decode > 0:
+            lib.paged_attention_decode(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens, meta.num_decode,
+                                       num_heads, num_kv_heads, scale, meta.decode_splits, meta.decode_workspace,
+                                       k_scale, v_scale)
+        if meta.num_prefill_tiles > 0:
+            lib.paged_attention_prefill(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
+                                        meta.query_start_loc, meta.prefill_tile_seq, meta.prefill_tile_q0,
+                                        meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale)
+        return out
+    B = meta.num_decode + meta.num_prefill
+    o = ref.paged_attention_ref(q.reshape(T, num_heads, head_dim), k_cache, v_cache, meta.block_tables[:B],
+                                meta.seq_lens[:B], meta.query_start_loc[:B + 1], scale, k_scale, v_scale)
+    if out is not None:
+        out.copy_(o)
+        return out
+    return o
+
+
+def sample(logits: torch.Tensor, temperature: torch.Tensor, top_p: torch.Tensor, top_k: torch.Tensor,
+           seeds: torch.Tensor, steps: torch.Tensor, noise: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Token ids ``[B]`` (int64).  ``seeds``/``steps`` (int64) key the per-request RNG stream."""
+    B = logits.shape[0]
+    if logits.is_cuda:
+        if out is None:
+            out = torch.empty(B, dtype=torch.int64, device=logits.device)
+        hip().sample(out, logits, temperature, top_p, top_k, seeds, steps, noise)
+        return out
+    if noise is None:
+        noise = torch.empty(B, logits.shape[1])
+        for i in range(B):          # same contract as the kernel: the draw depends on (seed, step) only
+            g = torch.Generator().manual_seed(int(seeds[i]) * 1000003 + int(steps[i]))
+            noise[i] = torch.rand(logits.shape[1], generator=g)
+        noise.clamp_(1e-10, 1 - 1e-7)
+    res = ref.sample_ref(logits, temperature, top_p, top_k.long(), uniform_noise=noise)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def copy_pages(cache: torch.Tensor, pairs: torch.Tensor) -> None:
+    """Copy-on-write helper: ``cache[dst] = cache[src]`` for every ``(src, dst)`` row of ``pairs``."""
+    if cache.is_cuda:
+        hip().copy_pages(cache, pairs)
+    else:
+        p = pairs.long()
+        if cache.dtype == torch.float8_e4m3fn:
+            c8 = cache.view(torch.uint8)
+            c8[p[:, 1]] = c8[p[:, 0]]
+        else:
+            cache[p[:, 1]] = cache[p[:, 0]]

@@ -1,0 +1,234 @@
+"""HIP kernel numerics vs the plain PyTorch fp32 references.
+
+Every test feeds the *same* bf16 inputs to the gfx950 kernel and to ``ops.reference`` and compares
+in fp32.  Shapes follow SURVEY.md §2.5 (Llama-3-8B: H 4096, 32/8 heads, D 128; 70B-TP8: G = 8).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from dli_amd import ops
+from dli_amd.ops import reference as ref
+from dli_amd.ops.kv_layout import allocate_kv_cache
+
+DEV = "cuda"
+
+
+def _bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+def test_extension_is_loaded():
+    ops.hip()
+    assert ops.hip_loaded()
+
+
+@pytest.mark.parametrize("T,H", [(1, 4096), (37, 4096), (256, 8192), (5, 16384), (3, 512)])
+def test_rms_norm(T, H):
+    x, w = _bf(T, H, seed=1), _bf(H, seed=2) * 0.1 + 1
+    got = ops.rms_norm(x, w, 1e-5).float()
+    want = ref.rms_norm_ref(x.float(), w.float(), 1e-5)
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+
+
+def test_rms_norm_strided_rows():
+    big = _bf(9, 3 * 4096, seed=3)
+    x = big[:, 4096:8192]
+    w = _bf(4096, seed=4)
+    torch.testing.assert_close(ops.rms_norm(x, w, 1e-5).float(), ref.rms_norm_ref(x.float(), w.float(), 1e-5),
+                               rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("T,H", [(1, 4096), (130, 4096), (64, 8192), (4, 16384)])
+def test_fused_add_rms_norm(T, H):
+    x, r, w = _bf(T, H, seed=5), _bf(T, H, seed=6), _bf(H, seed=7)
+    xs, rs = x.float(), r.float()
+    s = xs + rs
+    ops.fused_add_rms_norm(x, r, w, 1e-5)
+    torch.testing.assert_close(r.float(), s.to(torch.bfloat16).float(), rtol=0, atol=0)
+    torch.testing.assert_close(x.float(), ref.rms_norm_ref(s, w.float(), 1e-5), rtol=2e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("T,I", [(1, 14336), (77, 14336), (300, 1792), (2, 28672)])
+def test_silu_and_mul(T, I):
+    x = _bf(T, 2 * I, seed=8, scale=2.0)
+    torch.testing.assert_close(ops.silu_and_mul(x).float(), ref.silu_and_mul_ref(x.float()), rtol=2e-2, atol=2e-2)
+
+
+def _caches(nblocks, hkv, dtype=torch.bfloat16, layers=1):
+    return allocate_kv_cache(layers, nblocks, hkv, 128, dtype, DEV)[0]
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1), (4, 4)])
+@pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float8_e4m3fn])
+def test_rope_and_cache(Hq, Hkv, kv_dtype):
+    T, nblocks = 75, 16
+    qkv = _bf(T, (Hq + 2 * Hkv) * 128, seed=9)
+    pos = torch.randint(0, 4000, (T,), dtype=torch.int32, device=DEV)
+    slots = torch.randperm(nblocks * 32, device=DEV)[:T].to(torch.int32)
+    slots[5] = -1                                                   # padding token: no cache write
+    cs = ref.build_cos_sin_cache(4096, 128, 500000.0, DEV)
+    ks, vs = (0.05, 0.07) if kv_dtype == torch.float8_e4m3fn else (1.0, 1.0)
+    kc, vc = _caches(nblocks, Hkv, kv_dtype)
+    kc_ref, vc_ref = _caches(nblocks, Hkv, kv_dtype)
+    qkv_ref = qkv.clone()
+    ops.rope_and_cache(qkv, pos, cs, slots, kc, vc, Hq, Hkv, 128, ks, vs)
+    ref.rope_and_cache_ref(qkv_ref, pos, cs, slots, kc_ref, vc_ref, Hq, Hkv, 128, ks, vs)
+    torch.testing.assert_close(qkv.float(), qkv_ref.float(), rtol=2e-2, atol=2e-2)
+    if kv_dtype == torch.bfloat16:
+        torch.testing.assert_close(kc.float(), kc_ref.float(), rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(vc.float(), vc_ref.float(), rtol=0, atol=0)
+    else:                                                           # one e4m3 ulp = 12.5 %
+        torch.testing.assert_close(kc.float(), kc_ref.float(), rtol=0.13, atol=0.02)
+        torch.testing.assert_close(vc.float(), vc_ref.float(), rtol=0.13, atol=0.02)
+
+
+def _fill_cache(Hq, Hkv, seq_lens, kv_dtype, seed=0, scales=(1.0, 1.0)):
+    """Random K/V for every sequence written through the reference packer; returns caches + tables."""
+    g = torch.Generator().manual_seed(seed)
+    B = len(seq_lens)
+    max_blocks = max((L + 31) // 32 for L in seq_lens) + 1
+    nblocks = sum((L + 31) // 32 for L in seq_lens) + 4
+    kc, vc = _caches(nblocks, Hkv, kv_dtype)
+    perm = torch.randperm(nblocks, generator=g)
+    bt = torch.zeros(B, max_blocks, dtype=torch.int32)
+    used = 0
+    for i, L in enumerate(seq_lens):
+        nb = (L + 31) // 32
+        bt[i, :nb] = perm[used:used + nb].to(torch.int32)
+        used += nb
+        if L == 0:
+            continue
+        k = (torch.randn(L, Hkv, 128, generator=g)).to(torch.bfloat16).to(DEV)
+        v = (torch.randn(L, Hkv, 128, generator=g)).to(torch.bfloat16).to(DEV)
+        slots = (bt[i, :nb].long()[:, None] * 32 + torch.arange(32)[None, :]).reshape(-1)[:L].to(torch.int32).to(DEV)
+        from dli_amd.ops.kv_layout import write_kv_ref
+        write_kv_ref(k, v, slots, kc, vc, *scales)
+    return kc, vc, bt.to(DEV)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1), (16, 1)])
+@pytest.mark.parametrize("splits", [1, 3, 8])
+@pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float8_e4m3fn])
+def test_paged_attention_decode(Hq, Hkv, splits, kv_dtype):
+    seq_lens = [1, 31, 32, 33, 700, 2048, 129, 0, 1000]
+    scales = (0.5, 0.25) if kv_dtype == torch.float8_e4m3fn else (1.0, 1.0)
+    kc, vc, bt = _fill_cache(Hq, Hkv, seq_lens, kv_dtype, seed=11, scales=scales)
+    B = len(seq_lens)
+    qkv = _bf(B, (Hq + 2 * Hkv) * 128, seed=12)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    qsl = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(B * Hq * splits * 130, dtype=torch.float32, device=DEV)
+    meta = ops.AttnMetadata(num_decode=B, num_prefill=0, num_tokens=B, positions=None, slot_mapping=None,
+                            block_tables=bt, seq_lens=sl, query_start_loc=qsl, decode_splits=splits,
+                            decode_workspace=ws)
+    scale = 1 / math.sqrt(128)
+    got = ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, scale, *scales).float()
+    want = ref.paged_attention_ref(qkv[:, :Hq * 128].reshape(B, Hq, 128), kc, vc, bt, sl, qsl, scale, *scales).float()
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+    assert got[7].abs().max() == 0                                  # empty (padded) sequence → zeros
+
+
+def test_decode_softmax_rescale_branch():
+    """One key dominates late in the sequence: forces a large running-max jump (guide rule 26)."""
+    Hq, Hkv, L = 32, 8, 300
+    kc, vc, bt = _fill_cache(Hq, Hkv, [L], torch.bfloat16, seed=13)
+    qkv = _bf(1, (Hq + 2 * Hkv) * 128, seed=14)
+    q = qkv[:, :Hq * 128].reshape(1, Hq, 128)
+    # overwrite key 257 of every kv head with 6 × the matching query direction
+    from dli_amd.ops.kv_layout import write_kv_ref
+    k_spike = (q[0, ::4] * 6).reshape(1, Hkv, 128).to(torch.bfloat16)
+    v_spike = torch.full((1, Hkv, 128), 3.0, dtype=torch.bfloat16, device=DEV)
+    slot = (bt[0, 257 // 32].long() * 32 + 257 % 32).reshape(1).to(torch.int32)
+    write_kv_ref(k_spike, v_spike, slot, kc, vc)
+    sl = torch.tensor([L], dtype=torch.int32, device=DEV)
+    qsl = torch.tensor([0, 1], dtype=torch.int32, device=DEV)
+    meta = ops.AttnMetadata(1, 0, 1, None, None, bt, sl, qsl, decode_splits=1)
+    scale = 1 / math.sqrt(128)
+    got = ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, scale).float()
+    want = ref.paged_attention_ref(q, kc, vc, bt, sl, qsl, scale).float()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1), (4, 4), (4, 2)])
+@pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float8_e4m3fn])
+def test_paged_attention_prefill_and_mixed(Hq, Hkv, kv_dtype):
+    # (context length incl. new tokens, new tokens): fresh prompts, chunk continuations, 2 decodes first
+    seqs = [(500, 1), (64, 1), (300, 300), (1024, 200), (33, 17), (96, 96), (1500, 31), (16, 16)]
+    seq_lens = [s[0] for s in seqs]
+    qlens = [s[1] for s in seqs]
+    scales = (0.5, 0.25) if kv_dtype == torch.float8_e4m3fn else (1.0, 1.0)
+    kc, vc, bt = _fill_cache(Hq, Hkv, seq_lens, kv_dtype, seed=21, scales=scales)
+    T = sum(qlens)
+    qkv = _bf(T, (Hq + 2 * Hkv) * 128, seed=22)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    qsl = torch.tensor(np.concatenate([[0], np.cumsum(qlens)]), dtype=torch.int32, device=DEV)
+    tq = ops.prefill_tile_tokens(Hq, Hkv)
+    ts, t0 = ops.build_prefill_tiles(np.array(qlens[2:]), 2, tq)
+    meta = ops.AttnMetadata(num_decode=2, num_prefill=len(seqs) - 2, num_tokens=T, positions=None, slot_mapping=None,
+                            block_tables=bt, seq_lens=sl, query_start_loc=qsl, decode_splits=1,
+                            prefill_tile_seq=torch.from_numpy(ts).to(DEV), prefill_tile_q0=torch.from_numpy(t0).to(DEV),
+                            num_prefill_tiles=len(ts))
+    scale = 1 / math.sqrt(128)
+    got = ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, scale, *scales).float()
+    want = ref.paged_attention_ref(qkv[:, :Hq * 128].reshape(T, Hq, 128), kc, vc, bt, sl, qsl, scale, *scales).float()
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("V", [32000, 128256])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_sampler_matches_reference_with_shared_noise(V, dtype):
+    B = 12
+    g = torch.Generator().manual_seed(31)
+    logits = (torch.randn(B, V, generator=g) * 3).to(dtype).to(DEV)
+    temp = torch.tensor([0.0, 0.7, 1.0, 1.3, 0.7, 0.7, 1.0, 0.0, 0.9, 1.0, 0.5, 2.0], device=DEV)
+    top_p = torch.tensor([1.0, 1.0, 0.9, 0.5, 1.0, 0.95, 0.1, 0.9, 1.0, 0.8, 0.99, 0.7], device=DEV)
+    top_k = torch.tensor([0, 0, 0, 0, 40, 50, 0, 5, 1, 1000, 0, 3], dtype=torch.int32, device=DEV)
+    seeds = torch.arange(B, dtype=torch.int64, device=DEV)
+    steps = torch.zeros(B, dtype=torch.int64, device=DEV)
+    agree = 0
+    rounds = 6
+    for r in range(rounds):
+        noise = torch.rand(B, V, generator=g).clamp_(1e-10, 1 - 1e-7).to(DEV)
+        got = ops.sample(logits, temp, top_p, top_k, seeds, steps, noise=noise)
+        want = ref.sample_ref(logits, temp, top_p, top_k.long(), uniform_noise=noise)
+        agree += int((got == want).sum())
+        assert (got[[0, 7]] == logits.float().argmax(-1)[[0, 7]]).all()          # greedy rows
+        assert got[8] == logits[8].float().argmax()                                 # top_k = 1
+    assert agree >= rounds * B - 2, f"only {agree}/{rounds * B} draws agree with the reference"
+
+
+def test_sampler_philox_distribution_and_determinism():
+    V, N = 4096, 4096
+    probs = torch.tensor([0.5, 0.25, 0.125, 0.125])
+    logits = torch.full((N, V), -30.0)
+    logits[:, :4] = probs.log()
+    logits = logits.to(DEV)
+    one = torch.ones(N, device=DEV)
+    zk = torch.zeros(N, dtype=torch.int32, device=DEV)
+    seeds = torch.full((N,), 1234, dtype=torch.int64, device=DEV)
+    steps = torch.arange(N, dtype=torch.int64, device=DEV)
+    a = ops.sample(logits, one, one, zk, seeds, steps)
+    b = ops.sample(logits, one, one, zk, seeds, steps)
+    assert (a == b).all()                                           # same (seed, step) → same draw
+    freq = torch.bincount(a.cpu(), minlength=4)[:4].float() / N
+    assert (freq - probs).abs().max() < 0.03
+    c = ops.sample(logits, one, one * 0.7, zk, seeds, steps)        # nucleus 0.7 → tokens {0, 1} only
+    assert set(c.unique().tolist()) <= {0, 1}
+
+
+def test_copy_pages():
+    kc, _ = _caches(8, 2)
+    kc.copy_(torch.randn_like(kc.float()).to(torch.bfloat16))
+    want = kc.clone()
+    want[5] = want[1]
+    want[6] = want[2]
+    ops.copy_pages(kc, torch.tensor([[1, 5], [2, 6]], dtype=torch.int32, device=DEV))
+    assert torch.equal(kc, want)
