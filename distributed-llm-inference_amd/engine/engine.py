@@ -1,0 +1,141 @@
+"""``LLMEngine`` — the synchronous core: request intake, one ``step()`` = schedule → execute →
+sample → advance, output records for the streaming layer (SURVEY.md §3.6 hot loop).
+
+The reference has no engine (its server was an external Ollama box); the behaviours the
+harness relies on are produced here: one output record per generated token (→ one stream line), and
+honouring ``max_tokens`` / ``temperature`` (which Ollama ignored).
+"""
+from __future__ import annotations
+
+import itertools
+import time
+import zlib
+from typing import Optional
+
+import numpy as np
+
+from ..config import EngineConfig, KV_BLOCK_SIZE, SamplingParams
+from ..parallel.state import SINGLE, ParallelContext
+from ..runtime.block_manager import BlockManager
+from ..runtime.model_runner import ModelRunner
+from .metrics import EngineMetrics
+from .request import Request, RequestOutput, RequestStatus
+from .scheduler import Scheduler
+from .tokenizer import get_tokenizer
+
+
+class LLMEngine:
+    def __init__(self, cfg: EngineConfig, ctx: Optional[ParallelContext] = None, device=None):
+        self.cfg = cfg
+        self.ctx = ctx or SINGLE
+        self.runner = ModelRunner(cfg, self.ctx, device)
+        self.tokenizer = get_tokenizer(cfg.model, cfg.tokenizer_path)
+        self.metrics = EngineMetrics()
+        self.requests: dict[str, Request] = {}
+        self._seq_ids = itertools.count(1)
+        if self.ctx.is_driver:
+            self.bm = BlockManager(self.runner.num_blocks, KV_BLOCK_SIZE, cfg.cache.enable_prefix_caching)
+            self.scheduler = Scheduler(cfg.sched, self.bm)
+        else:
+            self.bm = None
+            self.scheduler = None
+
+    # ------------------------------------------------------------------ intake
+    def add_request(self, req_id: str, prompt=None, params: Optional[SamplingParams] = None, prompt_ids=None,
+                    arrival: Optional[float] = None, client_tag=None) -> Request:
+        if req_id in self.requests:
+            raise ValueError(f"duplicate request id {req_id!r}")
+        if prompt_ids is None:
+            prompt_ids = self.tokenizer.encode(prompt or "")
+        max_len = self.cfg.sched.max_model_len
+        if len(prompt_ids) >= max_len:                      # keep the tail, leave room for one token
+            prompt_ids = prompt_ids[-(max_len - 1):]
+        vocab = self.cfg.model.vocab_size
+        prompt_ids = np.asarray(prompt_ids, dtype=np.int64) % vocab
+        params = (params or SamplingParams()).clamp(max_len, len(prompt_ids))
+        req = Request(req_id, next(self._seq_ids), prompt_ids, params, arrival, client_tag)
+        if params.seed is None:
+            req.seed = (zlib.crc32(req_id.encode()) ^ (self.cfg.seed * 0x9E3779B1)) & 0x7FFFFFFF
+        self.requests[req_id] = req
+        self.scheduler.add(req)
+        self.metrics.on_arrival(req)
+        return req
+
+    def abort_request(self, req_id: str) -> bool:
+        req = self.requests.pop(req_id, None)
+        if req is None:
+            return False
+        self.scheduler.abort(req_id)
+        self.metrics.on_finish(req, aborted=True)
+        return True
+
+    def has_unfinished(self) -> bool:
+        return self.scheduler.has_work()
+
+    @property
+    def num_running(self) -> int:
+        return len(self.scheduler.running)
+
+    @property
+    def num_waiting(self) -> int:
+        return len(self.scheduler.waiting)
+
+    def outstanding_tokens(self) -> int:
+        """Load figure used by the DP router: tokens still to be computed or generated."""
+        tot = 0
+        for r in self.requests.values():
+            tot += (r.num_tokens - r.num_computed) + max(r.params.max_tokens - r.num_output, 0)
+        return tot
+
+    # ------------------------------------------------------------------ one step
+    def step(self) -> list[RequestOutput]:
+        t0 = time.perf_counter()
+        batch = self.scheduler.schedule()
+        if batch is None:
+            return []
+        t1 = time.perf_counter()
+        for r in batch.requests:
+            if r.first_scheduled is None:
+                r.first_scheduled = t1
+        sampled = self.runner.execute(batch, self.bm)
+        t2 = time.perf_counter()
+        results = self.scheduler.update(batch, sampled, self.cfg.model.eos_token_id, self.cfg.sched.max_model_len)
+        outs = []
+        for req, tok, status in results:
+            if tok is None:
+                continue
+            if req.first_token_time is None:
+                req.first_token_time = t2
+            req.last_token_time = t2
+            fin = status is not None
+            if fin:
+                req.finish_time = t2
+                self.requests.pop(req.req_id, None)
+                self.metrics.on_finish(req)
+            outs.append(RequestOutput(req.req_id, [tok], fin, status.value if fin else None, req.num_prompt,
+                                      req.num_output, req.num_cached_prompt, req.client_tag))
+        self.metrics.on_step(batch, t1 - t0, t2 - t1, time.perf_counter() - t2, self)
+        return outs
+
+    # ------------------------------------------------------------------ conveniences
+    def generate(self, prompts, params: Optional[SamplingParams] = None, prompt_ids=None) -> list[list[int]]:
+        """Offline helper: run a list of prompts to completion, return the generated ids per prompt."""
+        n = len(prompts) if prompts is not None else len(prompt_ids)
+        ids = []
+        for i in range(n):
+            rid = f"gen-{next(self._seq_ids)}-{i}"
+            ids.append(rid)
+            self.add_request(rid, None if prompts is None else prompts[i], params,
+                             None if prompt_ids is None else prompt_ids[i])
+        reqs = {rid: self.requests[rid] for rid in ids}
+        while self.has_unfinished():
+            self.step()
+        return [reqs[rid].output_ids.tolist() for rid in ids]
+
+    def warmup(self, capture_graphs: bool = True):
+        """Compile/capture everything that would otherwise hit the first requests' latency."""
+        if capture_graphs:
+            self.runner.capture_all()
+
+    def shutdown(self):
+        self.runner.shutdown_workers()

@@ -1,0 +1,164 @@
+"""Continuous-batching scheduler with chunked prefill over the paged KV cache.
+
+North-star item (1) of BASELINE.json; the reference's server side was a black box that served
+requests strictly one at a time — this scheduler exists to remove that
+head-of-line blocking under BurstGPT-style bursts.
+
+Policy, one call per engine step:
+
+1. **Running sequences first** (FCFS order): each decode gets its one token; an unfinished prefill
+   gets up to ``long_prefill_chunk`` tokens.  All share the step's ``max_num_batched_tokens`` budget,
+   so a burst of new prompts can never starve token generation of already admitted requests (bounds
+   TPOT), while decodes leave the rest of the budget to prefill (bounds TTFT).
+2. **Admission** of waiting requests while budget, sequence slots and KV pages (above a small
+   watermark) remain.  On first admission the prompt is matched against the prefix cache, so
+   multi-turn prompts skip their shared prefix.
+3. **Preemption by recompute**: if a running sequence cannot get a page, the most recently admitted
+   sequence is evicted (pages freed, progress reset, put at the head of the waiting queue).  With
+   288 GB of HBM recompute is cheaper than swap.
+
+KV accounting lives in the C++ ``BlockManager`` (``csrc/runtime/block_manager.cpp``).
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Optional
+
+import numpy as np
+
+from ..config import SchedulerConfig
+from .request import Request, RequestStatus, ScheduledBatch
+
+
+class Scheduler:
+    def __init__(self, cfg: SchedulerConfig, block_manager, watermark: float = 0.01):
+        self.cfg = cfg
+        self.bm = block_manager
+        self.waiting: deque[Request] = deque()
+        self.running: list[Request] = []
+        self.watermark_blocks = max(int(block_manager.num_blocks * watermark), 1)
+        self.num_preemptions = 0
+
+    # ------------------------------------------------------------------ queue management
+    def add(self, req: Request) -> None:
+        self.waiting.append(req)
+
+    def abort(self, req_id: str) -> Optional[Request]:
+        for q in (self.running, self.waiting):
+            for r in q:
+                if r.req_id == req_id:
+                    q.remove(r)
+                    self._release(r, RequestStatus.FINISHED_ABORTED)
+                    return r
+        return None
+
+    def has_work(self) -> bool:
+        return bool(self.waiting or self.running)
+
+    def _release(self, req: Request, status: RequestStatus) -> None:
+        self.bm.free_seq(req.seq_id)
+        req.status = status
+
+    def finish(self, req: Request, status: RequestStatus) -> None:
+        if req in self.running:
+            self.running.remove(req)
+        # publish the generated text too: the next turn of a conversation re-sends it as a prefix
+        self.bm.commit(req.seq_id, req.all_ids, req.num_computed)
+        self._release(req, status)
+
+    def _preempt(self, req: Request) -> None:
+        self.bm.free_seq(req.seq_id)
+        req.num_computed = 0
+        req.status = RequestStatus.PREEMPTED
+        req.preemptions += 1
+        self.num_preemptions += 1
+        self.waiting.appendleft(req)
+
+    # ------------------------------------------------------------------ one step
+    def schedule(self) -> Optional[ScheduledBatch]:
+        cfg = self.cfg
+        budget = cfg.max_num_batched_tokens
+        picked: list[tuple[Request, int]] = []
+        preempted: list[Request] = []
+
+        # 1) running sequences
+        i = 0
+        while i < len(self.running) and budget > 0:
+            req = self.running[i]
+            n_new = min(req.num_tokens - req.num_computed, cfg.long_prefill_chunk, budget)
+            ok = True
+            while not self.bm.allocate(req.seq_id, req.num_computed + n_new):
+                victim = self.running.pop()                # most recently admitted
+                self._preempt(victim)
+                preempted.append(victim)
+                if victim is req:
+                    ok = False
+                    break
+                # a victim scheduled earlier in this step cannot exist: victims come from the tail
+            if not ok:
+                break
+            picked.append((req, n_new))
+            budget -= n_new
+            i += 1
+
+        # 2) admission (never in a step that had to preempt)
+        if not preempted:
+            while self.waiting and budget > 0 and len(self.running) < cfg.max_num_seqs:
+                req = self.waiting[0]
+                if not self.bm.has_seq(req.seq_id):
+                    cached = self.bm.match_prefix(req.seq_id, req.all_ids)
+                    req.num_computed = cached
+                    if req.preemptions == 0:
+                        req.num_cached_prompt = cached
+                remaining = req.num_tokens - req.num_computed
+                n_new = min(remaining, cfg.long_prefill_chunk, budget)
+                if not cfg.enable_chunked_prefill and n_new < remaining:
+                    break
+                need_total = req.num_computed + n_new
+                free_after = self.bm.num_free - max((need_total + self.bm.block_size - 1) // self.bm.block_size
+                                                    - len(self.bm.block_table(req.seq_id)), 0)
+                if free_after < self.watermark_blocks or not self.bm.allocate(req.seq_id, need_total):
+                    break
+                self.waiting.popleft()
+                req.status = RequestStatus.RUNNING
+                self.running.append(req)
+                picked.append((req, n_new))
+                budget -= n_new
+
+        if not picked:
+            return None
+        # decodes (single token) first, stable otherwise
+        picked.sort(key=lambda p: p[1] != 1)
+        reqs = [p[0] for p in picked]
+        num_new = np.fromiter((p[1] for p in picked), dtype=np.int32, count=len(picked))
+        num_decode = int((num_new == 1).sum())
+        sample_mask = np.fromiter((r.num_computed + n == r.num_tokens for r, n in picked), dtype=bool, count=len(picked))
+        return ScheduledBatch(reqs, num_new, num_decode, int(num_new.sum()), sample_mask, preempted)
+
+    # ------------------------------------------------------------------ after the forward pass
+    def update(self, batch: ScheduledBatch, sampled: np.ndarray, eos_token_id: int, max_model_len: int):
+        """Advance the scheduled sequences; returns ``[(request, new_token or None, finished_status or None)]``."""
+        out = []
+        j = 0
+        for req, n_new, samples in zip(batch.requests, batch.num_new, batch.sample_mask):
+            req.num_computed += int(n_new)
+            tok = None
+            status = None
+            if samples:
+                tok = int(sampled[j])
+                j += 1
+                req.append(tok)
+                p = req.params
+                if (not p.ignore_eos) and (tok == eos_token_id or tok in p.stop_token_ids):
+                    status = RequestStatus.FINISHED_STOPPED
+                elif req.num_output >= p.max_tokens or req.num_tokens >= max_model_len:
+                    status = RequestStatus.FINISHED_LENGTH
+            elif req.num_computed % (8 * self.bm.block_size) < n_new:
+                # a long prefill crossed a multiple of 8 pages: publish its full pages early
+                self.bm.commit(req.seq_id, req.all_ids, req.num_computed)
+            if req.num_computed == req.num_prompt and samples:
+                self.bm.commit(req.seq_id, req.all_ids, req.num_computed)     # prompt complete
+            if status is not None:
+                self.finish(req, status)
+            out.append((req, tok, status))
+        return out

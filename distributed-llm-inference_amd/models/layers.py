@@ -1,0 +1,150 @@
+"""Tensor-parallel building blocks shared by the model families.
+
+Sharding follows the usual Megatron layout, chosen so that one transformer layer needs exactly two
+all-reduces (after the attention output projection and after the MLP/MoE down projection):
+
+* ``ColumnParallelLinear`` – output features split over TP ranks (QKV by heads, gate/up by columns);
+* ``RowParallelLinear``    – input features split, partial sums all-reduced over xGMI (RCCL or the
+  custom one-/two-shot kernel);
+* ``VocabParallelEmbedding`` / ``ParallelLMHead`` – vocabulary split, embedding all-reduced, logits
+  all-gathered.
+
+Weights are plain ``[out, in]`` tensors consumed by ``torch.nn.functional.linear`` (hipBLASLt on
+ROCm — SURVEY.md §2.5 K11: dense GEMMs stay on the vendor library).  Random initialisation is
+deterministic per parameter *name* and generated at full (unsharded) shape before slicing, so a TP=k
+model holds exactly the shards of the TP=1 model with the same seed — the property the
+TP-equivalence tests rely on.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..parallel.state import ParallelContext
+
+
+def _param_seed(base_seed: int, name: str) -> int:
+    return (base_seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 31 - 1)
+
+
+def random_full_tensor(name: str, shape, dtype, device, seed: int, std: float = 0.02) -> torch.Tensor:
+    """The *unsharded* random parameter ``name`` (same values whatever the TP degree)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(_param_seed(seed, name))
+    return (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+
+
+class Weight(nn.Module):
+    """A parameter holder that knows how to cut its shard out of the full tensor."""
+
+    def __init__(self, full_shape, shard_dim: Optional[int], ctx: ParallelContext, dtype, device,
+                 segments: Optional[list] = None):
+        super().__init__()
+        self.full_shape = tuple(full_shape)
+        self.shard_dim = shard_dim
+        self.ctx = ctx
+        # `segments`: sizes of independently sharded pieces along shard_dim (q|k|v or gate|up)
+        self.segments = segments or ([self.full_shape[shard_dim]] if shard_dim is not None else None)
+        shape = list(self.full_shape)
+        if shard_dim is not None:
+            for s in self.segments:
+                assert s % ctx.tp_size == 0, f"segment {s} not divisible by tp={ctx.tp_size}"
+            shape[shard_dim] = sum(s // ctx.tp_size for s in self.segments)
+        self.data = nn.Parameter(torch.empty(shape, dtype=dtype, device=device), requires_grad=False)
+
+    def shard_of(self, full: torch.Tensor) -> torch.Tensor:
+        if self.shard_dim is None or self.ctx.tp_size == 1:
+            return full
+        parts, start = [], 0
+        for s in self.segments:
+            per = s // self.ctx.tp_size
+            parts.append(full.narrow(self.shard_dim, start + self.ctx.tp_rank * per, per))
+            start += s
+        return torch.cat(parts, dim=self.shard_dim) if len(parts) > 1 else parts[0]
+
+    def load_full(self, full: torch.Tensor):
+        assert tuple(full.shape) == self.full_shape, f"expected {self.full_shape}, got {tuple(full.shape)}"
+        self.data.copy_(self.shard_of(full).to(self.data.dtype))
+
+    def init_random(self, name: str, seed: int, std: float = 0.02):
+        self.load_full(random_full_tensor(name, self.full_shape, self.data.dtype, self.data.device, seed, std))
+
+    def init_const(self, value: float):
+        self.data.fill_(value)
+
+
+class ColumnParallelLinear(nn.Module):
+    def __init__(self, in_features: int, out_segments: list, ctx: ParallelContext, dtype, device, bias: bool = False):
+        super().__init__()
+        self.weight = Weight((sum(out_segments), in_features), 0, ctx, dtype, device, segments=list(out_segments))
+        self.bias = Weight((sum(out_segments),), 0, ctx, dtype, device, segments=list(out_segments)) if bias else None
+
+    def forward(self, x):
+        return F.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
+
+
+class RowParallelLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, ctx: ParallelContext, dtype, device, bias: bool = False,
+                 reduce: bool = True):
+        super().__init__()
+        self.ctx = ctx
+        self.reduce = reduce
+        self.weight = Weight((out_features, in_features), 1, ctx, dtype, device)
+        self.bias = Weight((out_features,), None, ctx, dtype, device) if bias else None
+
+    def forward(self, x):
+        # the bias must be added once, not tp times: only rank 0 adds it before the reduction
+        b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
+        y = F.linear(x, self.weight.data, b)
+        return self.ctx.all_reduce(y) if self.reduce else y
+
+
+class ReplicatedLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, ctx: ParallelContext, dtype, device, bias: bool = False):
+        super().__init__()
+        self.weight = Weight((out_features, in_features), None, ctx, dtype, device)
+        self.bias = Weight((out_features,), None, ctx, dtype, device) if bias else None
+
+    def forward(self, x):
+        return F.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
+
+
+class VocabParallelEmbedding(nn.Module):
+    def __init__(self, vocab_size: int, hidden: int, ctx: ParallelContext, dtype, device):
+        super().__init__()
+        self.ctx = ctx
+        self.vocab_padded = (vocab_size + ctx.tp_size - 1) // ctx.tp_size * ctx.tp_size
+        self.vocab_size = vocab_size
+        self.weight = Weight((self.vocab_padded, hidden), 0, ctx, dtype, device)
+        self.per = self.vocab_padded // ctx.tp_size
+
+    def forward(self, ids: torch.Tensor):
+        if self.ctx.tp_size == 1:
+            return F.embedding(ids, self.weight.data)
+        lo = self.ctx.tp_rank * self.per
+        local = ids - lo
+        mine = (local >= 0) & (local < self.per)
+        out = F.embedding(torch.where(mine, local, torch.zeros_like(local)), self.weight.data)
+        out = out * mine.unsqueeze(-1).to(out.dtype)
+        return self.ctx.all_reduce(out)
+
+
+class ParallelLMHead(nn.Module):
+    """Logits over the full vocabulary: local ``[n, V/tp]`` GEMM, then an all-gather."""
+
+    def __init__(self, embedding: VocabParallelEmbedding, tied: bool, hidden: int, ctx: ParallelContext, dtype, device):
+        super().__init__()
+        self.ctx = ctx
+        self.vocab_size = embedding.vocab_size
+        self.tied = tied
+        self._embedding = [embedding]          # not registered twice when tied
+        self.weight = None if tied else Weight((embedding.vocab_padded, hidden), 0, ctx, dtype, device)
+
+    def forward(self, h: torch.Tensor) -> torch.Tensor:
+        w = self._embedding[0].weight.data if self.tied else self.weight.data
+        logits = self.ctx.all_gather_last_dim(F.linear(h, w))
+        return logits[..., :self.vocab_size] if logits.shape[-1] != self.vocab_size else logits

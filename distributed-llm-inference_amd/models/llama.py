@@ -1,0 +1,158 @@
+"""Llama-3 (8B / 70B) and Mixtral-8x7B decoder stacks over the paged KV cache.
+
+Per layer:  fused_add_rmsnorm → QKV GEMM → rope+cache write → paged attention →
+O GEMM (+all-reduce) → fused_add_rmsnorm → gate/up GEMM → SwiGLU → down GEMM (+all-reduce); Mixtral
+replaces the dense MLP by the top-2 MoE block.  Everything between the GEMMs is a hand-written HIP
+kernel (``dli_amd.ops``); the GEMMs are hipBLASLt through torch.
+
+Expert parallelism (``ctx.ep_size == tp``): each rank owns ``E/tp`` whole experts.  Activations are
+already replicated across the TP group after the attention all-reduce, so no all-to-all dispatch is
+needed — every rank evaluates its own experts on the tokens routed to them and the existing
+all-reduce sums the partial outputs (the "all-gather + local mask" variant noted in SURVEY.md §2.5 K8).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import ModelConfig
+from ..ops.reference import attention_scale, build_cos_sin_cache
+from ..parallel.state import ParallelContext
+from .layers import (ColumnParallelLinear, ParallelLMHead, ReplicatedLinear, RowParallelLinear,
+                     VocabParallelEmbedding, Weight)
+
+
+class Attention(nn.Module):
+    def __init__(self, cfg: ModelConfig, ctx: ParallelContext, dtype, device, bias: bool = False, rope: bool = True):
+        super().__init__()
+        tp = ctx.tp_size
+        assert cfg.num_heads % tp == 0 and cfg.num_kv_heads % tp == 0, \
+            f"tp={tp} must divide heads ({cfg.num_heads}) and kv heads ({cfg.num_kv_heads})"
+        self.hq, self.hkv, self.d = cfg.num_heads // tp, cfg.num_kv_heads // tp, cfg.head_dim
+        self.qkv = ColumnParallelLinear(cfg.hidden_size,
+                                        [cfg.num_heads * self.d, cfg.num_kv_heads * self.d, cfg.num_kv_heads * self.d],
+                                        ctx, dtype, device, bias=bias)
+        self.o = RowParallelLinear(cfg.num_heads * self.d, cfg.hidden_size, ctx, dtype, device, bias=bias)
+        self.scale = attention_scale(self.d)
+        self.rope = rope
+        self.k_scale = 1.0
+        self.v_scale = 1.0
+
+    def forward(self, h, meta, kv, cos_sin):
+        qkv = self.qkv(h)
+        k_cache, v_cache = kv
+        ops.rope_and_cache(qkv, meta.positions, cos_sin if self.rope else None, meta.slot_mapping, k_cache, v_cache,
+                           self.hq, self.hkv, self.d, self.k_scale, self.v_scale)
+        a = ops.paged_attention(qkv, k_cache, v_cache, meta, self.hq, self.hkv, self.d, self.scale,
+                                self.k_scale, self.v_scale)
+        return self.o(a)
+
+
+class SwiGLUMLP(nn.Module):
+    def __init__(self, cfg: ModelConfig, ctx: ParallelContext, dtype, device):
+        super().__init__()
+        self.gate_up = ColumnParallelLinear(cfg.hidden_size, [cfg.intermediate_size, cfg.intermediate_size],
+                                            ctx, dtype, device)
+        self.down = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, ctx, dtype, device)
+
+    def forward(self, h):
+        return self.down(ops.silu_and_mul(self.gate_up(h)))
+
+
+class MoEBlock(nn.Module):
+    """Mixtral sparse MLP: router (replicated) + experts, expert- or tensor-parallel."""
+
+    def __init__(self, cfg: ModelConfig, ctx: ParallelContext, dtype, device):
+        super().__init__()
+        self.ctx = ctx
+        self.top_k = cfg.top_k_experts
+        self.num_experts = cfg.num_experts
+        self.router = ReplicatedLinear(cfg.hidden_size, cfg.num_experts, ctx, dtype, device)
+        E, I, H = cfg.num_experts, cfg.intermediate_size, cfg.hidden_size
+        if ctx.ep_size > 1:
+            assert E % ctx.tp_size == 0
+            self.local_experts = E // ctx.tp_size
+            self.expert_offset = ctx.tp_rank * self.local_experts
+            self.w13 = Weight((E, 2 * I, H), 0, ctx, dtype, device)                  # whole experts per rank
+            self.w2 = Weight((E, H, I), 0, ctx, dtype, device)
+        else:
+            self.local_experts, self.expert_offset = E, 0
+            self.w13 = Weight((E, 2 * I, H), 1, ctx, dtype, device, segments=[I, I])  # gate|up columns split
+            self.w2 = Weight((E, H, I), 2, ctx, dtype, device)
+
+    def forward(self, h):
+        logits = self.router(h)
+        out = ops.fused_moe(h, logits, self.w13.data, self.w2.data, self.top_k, self.expert_offset)
+        return self.ctx.all_reduce(out)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, cfg: ModelConfig, ctx: ParallelContext, dtype, device):
+        super().__init__()
+        H = cfg.hidden_size
+        self.eps = cfg.rms_eps
+        self.input_norm = Weight((H,), None, ctx, dtype, device)
+        self.post_norm = Weight((H,), None, ctx, dtype, device)
+        self.attn = Attention(cfg, ctx, dtype, device)
+        self.mlp = MoEBlock(cfg, ctx, dtype, device) if cfg.num_experts > 0 else SwiGLUMLP(cfg, ctx, dtype, device)
+
+    def forward(self, h, residual, meta, kv, cos_sin):
+        if residual is None:
+            residual = h
+            h = ops.rms_norm(h, self.input_norm.data, self.eps)
+        else:
+            ops.fused_add_rms_norm(h, residual, self.input_norm.data, self.eps)
+        h = self.attn(h, meta, kv, cos_sin)
+        ops.fused_add_rms_norm(h, residual, self.post_norm.data, self.eps)
+        h = self.mlp(h)
+        return h, residual
+
+
+class LlamaForCausalLM(nn.Module):
+    """Also serves Mixtral (``cfg.num_experts > 0``)."""
+
+    def __init__(self, cfg: ModelConfig, ctx: ParallelContext, dtype, device):
+        super().__init__()
+        self.cfg, self.ctx = cfg, ctx
+        self.embed = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size, ctx, dtype, device)
+        self.layers = nn.ModuleList(DecoderLayer(cfg, ctx, dtype, device) for _ in range(cfg.num_layers))
+        self.final_norm = Weight((cfg.hidden_size,), None, ctx, dtype, device)
+        self.lm_head = ParallelLMHead(self.embed, cfg.tie_embeddings, cfg.hidden_size, ctx, dtype, device)
+        self.register_buffer("cos_sin", build_cos_sin_cache(cfg.max_position, cfg.head_dim, cfg.rope_theta, device),
+                             persistent=False)
+
+    @property
+    def local_kv_heads(self) -> int:
+        return self.cfg.num_kv_heads // self.ctx.tp_size
+
+    def forward(self, input_ids: torch.Tensor, meta, kv_caches) -> torch.Tensor:
+        h = self.embed(input_ids)
+        residual = None
+        for layer, kv in zip(self.layers, kv_caches):
+            h, residual = layer(h, residual, meta, kv, self.cos_sin)
+        ops.fused_add_rms_norm(h, residual, self.final_norm.data, self.cfg.rms_eps)
+        return h
+
+    def compute_logits(self, h: torch.Tensor) -> torch.Tensor:
+        return self.lm_head(h)
+
+    # ---- parameter naming (HF checkpoint names → modules) used by init and the safetensors loader
+    def named_weights(self):
+        yield "model.embed_tokens.weight", self.embed.weight, "normal"
+        for i, l in enumerate(self.layers):
+            p = f"model.layers.{i}."
+            yield p + "input_layernorm.weight", l.input_norm, "ones"
+            yield p + "post_attention_layernorm.weight", l.post_norm, "ones"
+            yield p + "self_attn.qkv_proj.weight", l.attn.qkv.weight, "normal"
+            yield p + "self_attn.o_proj.weight", l.attn.o.weight, "normal"
+            if isinstance(l.mlp, MoEBlock):
+                yield p + "block_sparse_moe.gate.weight", l.mlp.router.weight, "normal"
+                yield p + "block_sparse_moe.experts.w13", l.mlp.w13, "normal"
+                yield p + "block_sparse_moe.experts.w2", l.mlp.w2, "normal"
+            else:
+                yield p + "mlp.gate_up_proj.weight", l.mlp.gate_up.weight, "normal"
+                yield p + "mlp.down_proj.weight", l.mlp.down.weight, "normal"
+        yield "model.norm.weight", self.final_norm, "ones"
+        if self.lm_head.weight is not None:
+            yield "lm_head.weight", self.lm_head.weight, "normal"

@@ -192,3 +192,12 @@ def copy_pages(cache: torch.Tensor, pairs: torch.Tensor) -> None:
             c8[p[:, 1]] = c8[p[:, 0]]
         else:
             cache[p[:, 1]] = cache[p[:, 0]]
+
+
+def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int,
+              expert_offset: int = 0) -> torch.Tensor:
+    """Mixtral MoE block for the experts held by this rank (partial sum; caller all-reduces)."""
+    from . import moe as _moe
+    if x.is_cuda and _moe.hip_moe_supported(x, w13):
+        return _moe.fused_moe_hip(x, router_logits, w13, w2, top_k, expert_offset)
+    return ref.moe_ref(x, router_logits, w13, w2, top_k, expert_offset)

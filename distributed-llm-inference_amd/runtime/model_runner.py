@@ -1,0 +1,319 @@
+"""Model runner: owns the weights, the paged KV cache and the per-step device buffers; executes a
+``ScheduledBatch`` eagerly (mixed prefill/decode steps) or by replaying a captured hipGraph
+(pure-decode steps).
+
+Per step the host work is: C++ ``build_batch`` straight into pinned buffers → a handful of async H2D
+copies → kernels (or one graph launch) → one D2H of the sampled ids.  All kernels read their
+metadata from *static* device buffers, which is what makes the decode step capturable: a replay only
+needs the buffers refreshed, never new launch arguments.
+
+hipGraph buckets: one graph per padded batch size; padding rows have ``seq_len = 0`` and
+``slot = -1`` so the kernels skip them.  The KV-split count of the decode kernel is a launch
+dimension, hence fixed per bucket at capture time (small buckets → more splits).
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..config import EngineConfig, KV_BLOCK_SIZE
+from ..models import build_model, torch_dtype
+from ..ops import AttnMetadata
+from ..ops.kv_layout import allocate_kv_cache, bytes_per_block
+from ..parallel.state import SINGLE, ParallelContext
+
+
+def _pinned(shape, dtype, pin):
+    t = torch.zeros(shape, dtype=dtype)
+    return t.pin_memory() if pin else t
+
+
+class ModelRunner:
+    def __init__(self, cfg: EngineConfig, ctx: Optional[ParallelContext] = None, device: Optional[torch.device] = None):
+        self.cfg = cfg
+        self.ctx = ctx or SINGLE
+        if device is None:
+            use_gpu = cfg.device == "cuda" or (cfg.device == "auto" and torch.cuda.is_available())
+            device = torch.device("cuda", torch.cuda.current_device()) if use_gpu else torch.device("cpu")
+        self.device = device
+        self.on_gpu = device.type == "cuda"
+        mcfg = cfg.model
+        self.dtype = torch_dtype(mcfg.dtype)
+        if self.on_gpu and self.dtype != torch.bfloat16:
+            self.dtype = torch.bfloat16                      # the HIP kernels are bf16
+        t0 = time.perf_counter()
+        self.model = build_model(mcfg, self.ctx, device, self.dtype, cfg.seed, cfg.weights_path)
+        self.load_seconds = time.perf_counter() - t0
+        self.kv_dtype = torch.float8_e4m3fn if cfg.cache.kv_dtype == "fp8" else self.dtype
+        self.local_kv_heads = mcfg.num_kv_heads // self.ctx.tp_size
+        self.local_heads = mcfg.num_heads // self.ctx.tp_size
+        self.max_blocks_per_seq = (cfg.sched.max_model_len + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+        self.num_blocks = self._decide_num_blocks()
+        self.kv_caches = allocate_kv_cache(mcfg.num_layers, self.num_blocks, self.local_kv_heads, mcfg.head_dim,
+                                           self.kv_dtype, device)
+        self._alloc_buffers()
+        self.graphs: dict[int, tuple] = {}
+        self.graph_pool = None
+        self.tile_tokens = ops.prefill_tile_tokens(self.local_heads, self.local_kv_heads)
+        self.stats = {"graph_steps": 0, "eager_steps": 0}
+
+    # ------------------------------------------------------------------ sizing
+    def _decide_num_blocks(self) -> int:
+        c = self.cfg
+        m = c.model
+        per_block = bytes_per_block(m.num_layers, self.local_kv_heads, m.head_dim, self.kv_dtype)
+        if c.cache.num_blocks is not None:
+            return int(c.cache.num_blocks)
+        if not self.on_gpu:
+            return 2048
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info(self.device)
+        T = c.sched.max_num_batched_tokens
+        tp = self.ctx.tp_size
+        act = T * 2 * (4 * m.hidden_size + (m.num_heads + 2 * m.num_kv_heads) * m.head_dim // tp * 2
+                       + 3 * m.intermediate_size // tp * max(m.top_k_experts, 1))
+        logits = c.sched.max_num_seqs * m.vocab_size * 8
+        reserve = max(3 * (act + logits), 4 << 30) + (2 << 30)       # + graph pools
+        budget = free - (total * (1.0 - c.cache.gpu_memory_utilization)) - reserve
+        n = int(budget // per_block)
+        if n < self.max_blocks_per_seq:
+            raise RuntimeError(f"not enough HBM for the KV cache: {budget / 2**30:.1f} GiB left after weights")
+        return n
+
+    @property
+    def kv_cache_tokens(self) -> int:
+        return self.num_blocks * KV_BLOCK_SIZE
+
+    def _alloc_buffers(self):
+        """One packed int32 step buffer (pinned host + device mirror); every metadata tensor the kernels
+        read is a *view* into the device mirror, so a step needs a single H2D copy (and, under TP, a
+        single broadcast), and all addresses are static for hipGraph replay."""
+        s = self.cfg.sched
+        T, B = s.max_num_batched_tokens, s.max_num_seqs
+        self.max_T, self.max_B = T, B
+        max_tiles = T // 16 + B + 1
+        fields = [("input", T), ("pos", T), ("slot", T), ("seq_lens", B), ("qsl", B + 1), ("last", B),
+                  ("top_k", B), ("temp", B), ("top_p", B), ("seeds", 2 * B), ("steps", 2 * B),
+                  ("tile_seq", max_tiles), ("tile_q0", max_tiles), ("bt", B * self.max_blocks_per_seq)]
+        self.layout, off = {}, 0
+        for name, n in fields:
+            off = (off + 3) // 4 * 4                      # 16-byte aligned regions
+            self.layout[name] = (off, n)
+            off += n
+        total = (off + 3) // 4 * 4
+        self.h_buf = _pinned(total, torch.int32, self.on_gpu)
+        self.d_buf = torch.zeros(total, dtype=torch.int32, device=self.device)
+
+        def views(buf):
+            v = {k: buf[o:o + n] for k, (o, n) in self.layout.items()}
+            v["temp"], v["top_p"] = v["temp"].view(torch.float32), v["top_p"].view(torch.float32)
+            v["seeds"], v["steps"] = v["seeds"].view(torch.int64), v["steps"].view(torch.int64)
+            v["bt"] = v["bt"].view(B, self.max_blocks_per_seq)
+            return v
+
+        self.hv, self.dv = views(self.h_buf), views(self.d_buf)
+        self.nv = {k: t.numpy() for k, t in self.hv.items()}
+        self.n_input, self.n_pos, self.n_slot = self.nv["input"], self.nv["pos"], self.nv["slot"]
+        self.n_bt, self.n_seq_lens, self.n_qsl = self.nv["bt"], self.nv["seq_lens"], self.nv["qsl"]
+        self.d_sampled = torch.zeros(B, dtype=torch.int64, device=self.device)
+        self.h_sampled = _pinned(B, torch.int64, self.on_gpu)
+        max_splits = 16
+        self.decode_ws = (torch.empty(B * self.local_heads * max_splits * 130, dtype=torch.float32, device=self.device)
+                          if self.on_gpu else None)
+
+    # ------------------------------------------------------------------ batch → device
+    def _stage(self, batch, bm):
+        reqs = batch.requests
+        B, T = len(reqs), batch.total_tokens
+        nv = self.nv
+        seq_ids = np.fromiter((r.seq_id for r in reqs), dtype=np.int64, count=B)
+        computed = np.fromiter((r.num_computed for r in reqs), dtype=np.int32, count=B)
+        bm.build_batch(seq_ids, computed, batch.num_new, self.n_pos, self.n_slot, self.n_bt, self.n_seq_lens, self.n_qsl)
+        nd = batch.num_decode
+        if nd:
+            self.n_input[:nd] = np.fromiter((r.tokens[r.num_computed] for r in reqs[:nd]), dtype=np.int32, count=nd)
+        off = nd
+        for r, n in zip(reqs[nd:], batch.num_new[nd:]):
+            self.n_input[off:off + n] = r.tokens[r.num_computed:r.num_computed + n]
+            off += n
+        idx = np.flatnonzero(batch.sample_mask)
+        S = len(idx)
+        if S:
+            nv["last"][:S] = self.n_qsl[idx + 1] - 1
+            sel = [reqs[i] for i in idx]
+            nv["temp"][:S] = [r.params.temperature for r in sel]
+            nv["top_p"][:S] = [r.params.top_p for r in sel]
+            nv["top_k"][:S] = [r.params.top_k for r in sel]
+            nv["seeds"][:S] = [r.seed for r in sel]
+            nv["steps"][:S] = [r.num_output for r in sel]
+        n_tiles = 0
+        if B > nd:
+            ts, t0 = ops.build_prefill_tiles(batch.num_new[nd:], nd, self.tile_tokens)
+            n_tiles = len(ts)
+            nv["tile_seq"][:n_tiles] = ts
+            nv["tile_q0"][:n_tiles] = t0
+        return B, T, S, n_tiles
+
+    def _copy_in(self):
+        self.d_buf.copy_(self.h_buf, non_blocking=True)
+
+    def _meta(self, B, T, num_decode, max_seq_len, splits, n_tiles) -> AttnMetadata:
+        dv = self.dv
+        return AttnMetadata(num_decode=num_decode, num_prefill=B - num_decode, num_tokens=T,
+                            positions=dv["pos"][:T], slot_mapping=dv["slot"][:T], block_tables=dv["bt"],
+                            seq_lens=dv["seq_lens"], query_start_loc=dv["qsl"], max_seq_len=max_seq_len,
+                            decode_splits=splits, decode_workspace=self.decode_ws,
+                            prefill_tile_seq=dv["tile_seq"], prefill_tile_q0=dv["tile_q0"],
+                            num_prefill_tiles=n_tiles)
+
+    # ------------------------------------------------------------------ forward + sample
+    def _forward_sample(self, T, S, meta):
+        dv = self.dv
+        h = self.model(dv["input"][:T], meta, self.kv_caches)
+        if S == 0:
+            return
+        logits = self.model.compute_logits(h.index_select(0, dv["last"][:S]))
+        ops.sample(logits, dv["temp"][:S], dv["top_p"][:S], dv["top_k"][:S], dv["seeds"][:S], dv["steps"][:S],
+                   out=self.d_sampled[:S])
+
+    @torch.inference_mode()
+    def execute(self, batch, bm) -> np.ndarray:
+        """Driver-side step: stage the batch, (broadcast it to the TP workers,) run it; returns the
+        sampled token ids (one per ``sample_mask`` row)."""
+        B, T, S, n_tiles = self._stage(batch, bm)
+        nd = batch.num_decode
+        bucket = 0
+        if nd == B and S == B and self.on_gpu and self.cfg.use_hip_graphs:
+            bucket = self._bucket_for(B) or 0
+        splits = 1
+        if self.on_gpu and nd and not bucket:
+            splits = ops.choose_decode_splits(nd, self.local_kv_heads, int(self.n_seq_lens[:nd].max()))
+        header = (B, T, S, nd, n_tiles, bucket, splits)
+        if self.ctx.tp_size > 1:
+            self._broadcast_step(header)
+        return self.run_staged(header)
+
+    def _broadcast_step(self, header):
+        """Driver → workers: 7-int header over the CPU (gloo) group, packed step buffer over the
+        device group (RCCL broadcast of a few hundred KB)."""
+        import torch.distributed as dist
+        ctx = self.ctx
+        hdr = torch.tensor(header if header is not None else (-1,) * 7, dtype=torch.int64)
+        g = ctx.cpu_group if ctx.cpu_group is not None else ctx.group
+        dist.broadcast(hdr, src=dist.get_global_rank(g, 0), group=g)
+        if int(hdr[0]) < 0:
+            return None
+        if ctx.is_driver:
+            self._pad_for(tuple(int(x) for x in hdr))
+            self._copy_in()
+        dist.broadcast(self.d_buf, src=dist.get_global_rank(ctx.group, 0), group=ctx.group)
+        return tuple(int(x) for x in hdr)
+
+    def worker_step(self) -> bool:
+        """Worker-side step (TP rank > 0): wait for the driver's batch and execute it.  Returns False
+        when the driver signalled shutdown."""
+        header = self._broadcast_step(None)
+        if header is None:
+            return False
+        self.run_staged(header, staged_on_device=True)
+        return True
+
+    def shutdown_workers(self):
+        if self.ctx.tp_size > 1 and self.ctx.is_driver:
+            import torch.distributed as dist
+            g = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
+            dist.broadcast(torch.full((7,), -1, dtype=torch.int64), src=dist.get_global_rank(g, 0), group=g)
+
+    def _pad_for(self, header):
+        B, _T, _S, _nd, _nt, bucket, _sp = header
+        if bucket:
+            self._pad_decode(B, bucket)
+
+    @torch.inference_mode()
+    def run_staged(self, header, staged_on_device: bool = False) -> np.ndarray:
+        B, T, S, nd, n_tiles, bucket, splits = header
+        tp_staged = self.ctx.tp_size > 1                    # _broadcast_step already padded + copied
+        if bucket:
+            if not tp_staged:
+                self._pad_decode(B, bucket)
+                self._copy_in()
+            if bucket not in self.graphs:
+                self.capture_graph(bucket)
+            self.graphs[bucket][0].replay()
+            self.stats["graph_steps"] += 1
+            return self._fetch(B)
+        if not tp_staged:
+            self._copy_in()
+        meta = self._meta(B, T, nd, 0, splits, n_tiles)
+        self._forward_sample(T, S, meta)
+        self.stats["eager_steps"] += 1
+        return self._fetch(S)
+
+    def _fetch(self, S) -> np.ndarray:
+        if S == 0:
+            return np.zeros(0, dtype=np.int64)
+        if self.on_gpu:
+            self.h_sampled[:S].copy_(self.d_sampled[:S], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return self.h_sampled.numpy()[:S].copy()
+        return self.d_sampled[:S].numpy().copy()
+
+    # ------------------------------------------------------------------ hipGraph decode
+    def _bucket_for(self, B: int) -> Optional[int]:
+        for b in self.cfg.graph_batch_sizes:
+            if b >= B and b <= self.cfg.sched.max_num_seqs:
+                return b
+        return None
+
+    def _splits_for_bucket(self, bucket: int) -> int:
+        return ops.choose_decode_splits(bucket, self.local_kv_heads, min(self.cfg.sched.max_model_len, 2048))
+
+    def _pad_decode(self, B: int, bucket: int):
+        if bucket > B:
+            nv = self.nv
+            self.n_seq_lens[B:bucket] = 0
+            self.n_slot[B:bucket] = -1
+            self.n_pos[B:bucket] = 0
+            self.n_input[B:bucket] = 0
+            self.n_qsl[B + 1:bucket + 1] = np.arange(B + 1, bucket + 1)
+            nv["last"][B:bucket] = np.arange(B, bucket)
+            nv["temp"][B:bucket] = 0.0
+            nv["top_p"][B:bucket] = 1.0
+            nv["top_k"][B:bucket] = 0
+
+    def capture_graph(self, bucket: int):
+        """Capture one decode step at batch size ``bucket`` (inputs must be staged in the static buffers)."""
+        meta = self._meta(bucket, bucket, bucket, 0, self._splits_for_bucket(bucket), 0)
+        stream = torch.cuda.Stream(device=self.device)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):                      # warm-up outside capture (hipBLASLt workspaces, …)
+            for _ in range(2):
+                self._forward_sample(bucket, bucket, meta)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.graph_pool, stream=stream):
+            self._forward_sample(bucket, bucket, meta)
+        if self.graph_pool is None:
+            self.graph_pool = g.pool()
+        self.graphs[bucket] = (g, meta)
+        return g
+
+    def capture_all(self, buckets=None):
+        """Pre-capture the decode graphs (largest first so that the pool is sized once).  Under TP every
+        rank must call this with the same buckets (the captures contain collectives)."""
+        if not (self.on_gpu and self.cfg.use_hip_graphs):
+            return 0
+        todo = [b for b in (buckets or self.cfg.graph_batch_sizes) if b <= self.cfg.sched.max_num_seqs]
+        for bucket in sorted(todo, reverse=True):
+            if bucket in self.graphs:
+                continue
+            self._pad_decode(0, bucket)
+            self._copy_in()
+            self.capture_graph(bucket)
+        torch.cuda.synchronize()
+        return len(self.graphs)

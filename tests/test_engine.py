@@ -1,0 +1,203 @@
+"""Engine / scheduler / block-manager tests on CPU with tiny random-init models.
+
+The oracle for the paged, chunked, continuously-batched engine is a *dense* recomputation: the same
+model run on the whole sequence at once, one sequence at a time, greedy.
+"""
+import numpy as np
+import pytest
+import torch
+
+from dli_amd import ops
+from dli_amd.config import (CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config)
+from dli_amd.engine.engine import LLMEngine
+from dli_amd.runtime.block_manager import BlockManager
+
+
+def make_engine(model="tiny-llama", num_blocks=64, max_tokens=64, max_seqs=8, chunk=32, prefix=True, **kw):
+    cfg = EngineConfig(model=get_model_config(model), cache=CacheConfig(num_blocks=num_blocks, enable_prefix_caching=prefix),
+                       sched=SchedulerConfig(max_num_seqs=max_seqs, max_num_batched_tokens=max_tokens,
+                                             max_model_len=256, long_prefill_chunk=chunk),
+                       device="cpu", use_hip_graphs=False, **kw)
+    return LLMEngine(cfg)
+
+
+def dense_greedy(engine, prompt_ids, n_new):
+    """Oracle: every step re-runs the full sequence as one fresh prefill in a scratch cache."""
+    runner = engine.runner
+    model = runner.model
+    toks = list(prompt_ids)
+    out = []
+    for _ in range(n_new):
+        L = len(toks)
+        nb = (L + 31) // 32
+        caches = ops.allocate_kv_cache(engine.cfg.model.num_layers, nb, runner.local_kv_heads,
+                                       engine.cfg.model.head_dim, runner.kv_dtype, "cpu")
+        meta = ops.AttnMetadata(num_decode=0, num_prefill=1, num_tokens=L,
+                                positions=torch.arange(L, dtype=torch.int32),
+                                slot_mapping=torch.arange(L, dtype=torch.int32),
+                                block_tables=torch.arange(nb, dtype=torch.int32)[None],
+                                seq_lens=torch.tensor([L], dtype=torch.int32),
+                                query_start_loc=torch.tensor([0, L], dtype=torch.int32))
+        with torch.inference_mode():
+            h = model(torch.tensor(toks), meta, caches)
+            nxt = int(model.compute_logits(h[-1:]).float().argmax(-1))
+        toks.append(nxt)
+        out.append(nxt)
+    return out
+
+
+GREEDY = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True)
+
+
+@pytest.mark.parametrize("model", ["tiny-llama", "tiny-opt", "tiny-mixtral"])
+def test_engine_matches_dense_oracle(model):
+    eng = make_engine(model)
+    rng = np.random.default_rng(0)
+    prompts = [rng.integers(3, 500, size=n).tolist() for n in (5, 70, 33, 1, 100)]
+    got = eng.generate(None, GREEDY, prompt_ids=prompts)
+    for p, g in zip(prompts, got):
+        assert g == dense_greedy(eng, p, 12)
+    assert eng.bm.num_free == eng.bm.num_blocks          # everything released
+    assert eng.metrics.requests_finished == 5 and eng.metrics.generated_tokens == 60
+
+
+def test_chunked_prefill_and_token_budget_respected():
+    eng = make_engine(max_tokens=48, chunk=16)
+    rng = np.random.default_rng(1)
+    prompts = [rng.integers(3, 500, size=n).tolist() for n in (90, 60, 40)]
+    for i, p in enumerate(prompts):
+        eng.add_request(f"r{i}", prompt_ids=p, params=GREEDY)
+    seen_mixed = False
+    steps = 0
+    while eng.has_unfinished():
+        batch_before = eng.metrics.steps
+        eng.step()
+        steps += 1
+        assert eng.metrics.last_batch_tokens <= 48
+        assert eng.metrics.steps == batch_before + 1
+        seen_mixed |= eng.metrics.last_batch_seqs > 1
+    assert seen_mixed and steps > 12
+    # same answers as unchunked, one-at-a-time
+    ref = make_engine(max_tokens=256, chunk=256)
+    assert ref.generate(None, GREEDY, prompt_ids=prompts) == \
+        [dense_greedy(ref, p, 12) for p in prompts]
+
+
+def test_preemption_recompute_gives_same_tokens():
+    # 7 pages of 32 tokens: three 60-token prompts (2 pages each) + growth forces preemption
+    eng = make_engine(num_blocks=7, max_tokens=256, chunk=256, prefix=False)
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(3, 500, size=60).tolist() for _ in range(3)]
+    params = SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True)
+    got = eng.generate(None, params, prompt_ids=prompts)
+    assert eng.scheduler.num_preemptions > 0
+    big = make_engine(num_blocks=64, max_tokens=256, chunk=256, prefix=False)
+    assert got == big.generate(None, params, prompt_ids=prompts)
+    assert eng.bm.num_free == 7
+
+
+def test_prefix_cache_reuses_pages_and_keeps_results():
+    eng = make_engine()
+    rng = np.random.default_rng(3)
+    shared = rng.integers(3, 500, size=96).tolist()
+    a = shared + rng.integers(3, 500, size=10).tolist()
+    b = shared + rng.integers(3, 500, size=17).tolist()
+    out_a = eng.generate(None, GREEDY, prompt_ids=[a])[0]
+    hits_before = eng.bm.cache_hits
+    eng.add_request("b", prompt_ids=b, params=GREEDY)
+    req = eng.requests["b"]
+    while eng.has_unfinished():
+        eng.step()
+    assert eng.bm.cache_hits - hits_before == 3 and req.num_cached_prompt == 96
+    assert req.output_ids.tolist() == dense_greedy(eng, b, 12)
+    # multi-turn: prompt + generated answer is itself cached after the first turn
+    turn2 = a + out_a + rng.integers(3, 500, size=5).tolist()
+    eng.add_request("t2", prompt_ids=turn2, params=GREEDY)
+    r2 = eng.requests["t2"]
+    while eng.has_unfinished():
+        eng.step()
+    assert r2.num_cached_prompt >= 96 and r2.output_ids.tolist() == dense_greedy(eng, turn2, 12)
+    assert eng.metrics.cached_prompt_tokens >= 192
+
+
+def test_sampling_params_seeded_and_eos_and_abort():
+    eng = make_engine()
+    p = SamplingParams(temperature=0.8, top_p=0.9, top_k=50, max_tokens=10, seed=7, ignore_eos=True)
+    a = eng.generate(None, p, prompt_ids=[[5, 6, 7, 8]])[0]
+    b = eng.generate(None, p, prompt_ids=[[5, 6, 7, 8]])[0]
+    assert a == b and len(a) == 10                                  # per-request seeded stream
+    c = eng.generate(None, SamplingParams(temperature=0.8, max_tokens=10, seed=8, ignore_eos=True),
+                     prompt_ids=[[5, 6, 7, 8]])[0]
+    assert c != a
+    # EOS stops generation: make the greedy token the EOS by construction
+    first = eng.generate(None, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True), prompt_ids=[[9, 10]])[0][0]
+    eng.cfg.model.eos_token_id = first
+    out = eng.generate(None, SamplingParams(temperature=0.0, max_tokens=30), prompt_ids=[[9, 10]])[0]
+    assert out == [first]
+    # abort frees pages
+    eng.add_request("x", prompt_ids=list(range(3, 80)), params=SamplingParams(max_tokens=50, ignore_eos=True))
+    eng.step()
+    assert eng.bm.num_free < eng.bm.num_blocks
+    assert eng.abort_request("x") and not eng.has_unfinished()
+    assert eng.bm.num_free == eng.bm.num_blocks
+
+
+def test_max_model_len_truncates_prompt_and_generation():
+    eng = make_engine()
+    out = eng.generate(None, SamplingParams(temperature=0.0, max_tokens=500, ignore_eos=True),
+                       prompt_ids=[list(np.arange(3, 303) % 500)])[0]
+    assert 1 <= len(out) <= 2                                       # 255-token tail + room for 1 token
+
+
+# ------------------------------------------------------------------ block manager unit tests
+def test_block_manager_alloc_free_refcount_cow():
+    bm = BlockManager(8, 32, True)
+    toks = np.arange(100, dtype=np.int32)
+    assert bm.match_prefix(1, toks) == 0 and bm.allocate(1, 100)
+    assert bm.block_table(1) == [0, 1, 2, 3] and bm.num_free == 4
+    assert not bm.allocate(2, 32 * 5) and bm.num_free == 4          # all-or-nothing
+    bm.free_seq(2)
+    bm.fork(1, 3)
+    assert bm.ref_count(3) == 2
+    src, dst = bm.cow_tail(3, 100)                                  # tail page shared + partially filled
+    assert (src, dst) == (3, 4) and bm.ref_count(3) == 1 and bm.block_table(3) == [0, 1, 2, 4]
+    assert bm.cow_tail(3, 100) == (-1, -1) and bm.cow_tail(1, 96) == (-1, -1)
+    bm.free_seq(1)
+    bm.free_seq(3)
+    assert bm.num_free == 8
+
+
+def test_block_manager_prefix_cache_lru_eviction():
+    bm = BlockManager(4, 32, True)
+    a = np.arange(64, dtype=np.int32)
+    bm.match_prefix(1, a)
+    bm.allocate(1, 64)
+    bm.commit(1, a, 64)
+    bm.free_seq(1)
+    assert bm.num_free == 4 and bm.num_cached == 2                  # cached pages stay evictable
+    assert bm.match_prefix(2, np.concatenate([a, a[:5]])) == 64     # full hit on both pages
+    bm.free_seq(2)
+    assert bm.match_prefix(3, a) == 32                              # never the whole prompt
+    bm.free_seq(3)
+    b = np.arange(1000, 1128, dtype=np.int32)
+    bm.match_prefix(4, b)
+    assert bm.allocate(4, 128)                                      # needs all 4 pages → evicts the cache
+    assert bm.num_cached == 0 and bm.num_free == 0
+    bm.free_seq(4)
+    assert bm.match_prefix(5, a) == 0
+
+
+def test_build_batch_layout():
+    bm = BlockManager(16, 32, False)
+    bm.allocate(7, 40)
+    bm.allocate(9, 70)
+    pos, slot = np.zeros(64, np.int32), np.zeros(64, np.int32)
+    bt, sl, qs = np.zeros((4, 8), np.int32), np.zeros(4, np.int32), np.zeros(5, np.int32)
+    T = bm.build_batch(np.array([7, 9]), np.array([39, 60], np.int32), np.array([1, 10], np.int32), pos, slot, bt, sl, qs)
+    assert T == 11 and sl[:2].tolist() == [40, 70] and qs[:3].tolist() == [0, 1, 11]
+    assert pos[:11].tolist() == [39] + list(range(60, 70))
+    t7, t9 = bm.block_table(7), bm.block_table(9)
+    assert slot[0] == t7[1] * 32 + 7 and slot[1] == t9[1] * 32 + 28 and slot[5] == t9[2] * 32
+    assert bt[0, :2].tolist() == t7 and bt[1, :3].tolist() == t9
+    with pytest.raises(RuntimeError):
+        bm.build_batch(np.array([7]), np.array([39], np.int32), np.array([30], np.int32), pos, slot, bt, sl, qs)

@@ -201,7 +201,7 @@ def test_sampler_matches_reference_with_shared_noise(V, dtype):
         want = ref.sample_ref(logits, temp, top_p, top_k.long(), uniform_noise=noise)
         agree += int((got == want).sum())
         assert (got[[0, 7]] == logits.float().argmax(-1)[[0, 7]]).all()          # greedy rows
-        assert got[8] == logits[8].float().argmax()                                 # top_k = 1
+        assert logits[8, got[8]] == logits[8].max()                                 # top_k = 1 (bf16 ties allowed)
     assert agree >= rounds * B - 2, f"only {agree}/{rounds * B} draws agree with the reference"
 
 
