@@ -1,0 +1,244 @@
+"""Asynchronous front of the engine: the API event loop talks to an *engine core loop* through a
+pair of message channels ("thread/process boundary: API loop ⇄ engine loop").
+
+Two transports, one protocol:
+
+* ``mode="thread"``  – the core loop runs in a thread of this process (tests, CPU plumbing config);
+* ``mode="process"`` – the core loop runs in its own process that owns the GPU, so the per-token
+  Python work of the HTTP layer (detokenise, JSON, socket writes for thousands of concurrent
+  streams) never competes with the scheduler for the GIL.
+
+Messages to the core:   ("add", req_id, prompt_ids, params_dict, arrival) | ("abort", req_id) |
+                        ("stats",) | ("shutdown",)
+Messages from the core: ("out", [(req_id, token, finished, reason, n_prompt, n_out, n_cached), …]) —
+                        one message per engine step — | ("stats", dict) | ("ready", info) | ("dead", err)
+"""
+from __future__ import annotations
+
+import asyncio
+import dataclasses
+import multiprocessing as mp
+import queue
+import threading
+import time
+import traceback
+from typing import AsyncIterator, Optional
+
+from ..config import EngineConfig, SamplingParams
+
+
+# ------------------------------------------------------------------ core loop (thread or process)
+class _QueueChannel:
+    """Thread transport with the subset of the mp.Connection API the loops use."""
+
+    def __init__(self, rx: queue.SimpleQueue, tx: queue.SimpleQueue):
+        self.rx, self.tx = rx, tx
+
+    def send(self, msg):
+        self.tx.put(msg)
+
+    def poll(self, timeout: float = 0.0) -> bool:
+        if not self.rx.empty():
+            return True
+        if timeout <= 0:
+            return False
+        try:
+            item = self.rx.get(timeout=timeout)
+        except queue.Empty:
+            return False
+        self._peek = item
+        return True
+
+    def recv(self):
+        if getattr(self, "_peek", None) is not None:
+            item, self._peek = self._peek, None
+            return item
+        return self.rx.get()
+
+
+def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
+    """Runs until ("shutdown",): drain commands → one engine step → ship that step's tokens."""
+    def stats():
+        d = engine.metrics.snapshot()
+        d.update(outstanding_tokens=engine.outstanding_tokens(), num_running=engine.num_running,
+                 num_waiting=engine.num_waiting, kv_cache_tokens=engine.runner.kv_cache_tokens,
+                 graph_steps=engine.runner.stats["graph_steps"], eager_steps=engine.runner.stats["eager_steps"],
+                 prometheus=engine.metrics.render_prometheus())
+        return d
+
+    running = True
+    while running:
+        busy = engine.has_unfinished()
+        while chan.poll(0.0 if busy else idle_wait):
+            msg = chan.recv()
+            kind = msg[0]
+            if kind == "add":
+                _, rid, ids, pd, arrival = msg
+                try:
+                    engine.add_request(rid, prompt_ids=ids, params=SamplingParams(**pd), arrival=arrival)
+                except Exception as e:                       # bad request: report as finished-with-error
+                    chan.send(("out", [(rid, None, True, f"error: {e}", 0, 0, 0)]))
+            elif kind == "abort":
+                engine.abort_request(msg[1])
+            elif kind == "stats":
+                chan.send(("stats", stats()))
+            elif kind == "shutdown":
+                running = False
+                break
+            busy = True
+        if running and engine.has_unfinished():
+            outs = engine.step()
+            if outs:
+                chan.send(("out", [(o.req_id, o.new_token_ids[0], o.finished, o.finish_reason, o.num_prompt_tokens,
+                                    o.num_output_tokens, o.num_cached_tokens) for o in outs]))
+    engine.shutdown()
+
+
+def _process_main(cfg: EngineConfig, conn, device_index: int):
+    try:
+        import torch
+        if torch.cuda.is_available() and cfg.device != "cpu":
+            torch.cuda.set_device(device_index)
+        from .engine import LLMEngine
+        from ..runtime.tp_launcher import maybe_launch_tp
+        ctx = maybe_launch_tp(cfg, device_index)
+        engine = LLMEngine(cfg, ctx)
+        engine.warmup()
+        conn.send(("ready", {"kv_cache_tokens": engine.runner.kv_cache_tokens, "load_seconds": engine.runner.load_seconds}))
+        engine_core_loop(engine, conn)
+    except Exception:
+        conn.send(("dead", traceback.format_exc()))
+        raise
+
+
+# ------------------------------------------------------------------ API-side client
+@dataclasses.dataclass
+class StreamItem:
+    token: Optional[int]
+    finished: bool
+    reason: Optional[str]
+    n_prompt: int
+    n_out: int
+    n_cached: int
+
+
+class AsyncEngine:
+    def __init__(self, cfg: EngineConfig, mode: str = "thread", engine=None, device_index: int = 0):
+        self.cfg = cfg
+        self.mode = mode
+        self._streams: dict[str, asyncio.Queue] = {}
+        self._loop: Optional[asyncio.AbstractEventLoop] = None
+        self._stats_waiters: list[asyncio.Future] = []
+        self._dead: Optional[str] = None
+        self.info: dict = {}
+        if mode == "thread":
+            from .engine import LLMEngine
+            self.engine = engine or LLMEngine(cfg)
+            a, b = queue.SimpleQueue(), queue.SimpleQueue()
+            self._chan = _QueueChannel(rx=b, tx=a)                     # API side: send → a, receive ← b
+            core_chan = _QueueChannel(rx=a, tx=b)
+            self._core = threading.Thread(target=engine_core_loop, args=(self.engine, core_chan), daemon=True,
+                                          name="engine-core")
+            self.info = {"kv_cache_tokens": self.engine.runner.kv_cache_tokens}
+        elif mode == "process":
+            ctx = mp.get_context("spawn")
+            parent, child = ctx.Pipe(duplex=True)
+            self._chan = parent
+            self._core = ctx.Process(target=_process_main, args=(cfg, child, device_index), daemon=True,
+                                     name="engine-core")
+            self.engine = None
+        else:
+            raise ValueError(mode)
+        self._reader = threading.Thread(target=self._read_loop, daemon=True, name="engine-reader")
+
+    async def start(self, ready_timeout: float = 1800.0):
+        self._loop = asyncio.get_running_loop()
+        self._core.start()
+        if self.mode == "process":
+            t0 = time.time()
+            while not self._chan.poll(0.2):
+                if not self._core.is_alive():
+                    raise RuntimeError("engine process died during start-up")
+                if time.time() - t0 > ready_timeout:
+                    raise TimeoutError("engine process did not become ready")
+                await asyncio.sleep(0.05)
+            kind, payload = self._chan.recv()
+            if kind != "ready":
+                raise RuntimeError(f"engine process failed to start:\n{payload}")
+            self.info = payload
+        self._reader.start()
+
+    def _read_loop(self):
+        while True:
+            try:
+                msg = self._chan.recv()
+            except (EOFError, OSError):
+                self._loop.call_soon_threadsafe(self._on_dead, "engine channel closed")
+                return
+            if msg[0] == "bye":
+                return
+            self._loop.call_soon_threadsafe(self._dispatch, msg)
+
+    def _on_dead(self, why: str):
+        self._dead = why
+        for q in self._streams.values():
+            q.put_nowait(StreamItem(None, True, f"error: {why}", 0, 0, 0))
+
+    def _dispatch(self, msg):
+        kind = msg[0]
+        if kind == "out":
+            for rid, tok, fin, reason, n_p, n_o, n_c in msg[1]:
+                q = self._streams.get(rid)
+                if q is not None:
+                    q.put_nowait(StreamItem(tok, fin, reason, n_p, n_o, n_c))
+        elif kind == "stats":
+            for f in self._stats_waiters:
+                if not f.done():
+                    f.set_result(msg[1])
+            self._stats_waiters.clear()
+        elif kind == "dead":
+            self._on_dead(msg[1])
+
+    # ------------------------------------------------------------------ public API
+    async def generate(self, req_id: str, prompt_ids, params: SamplingParams) -> AsyncIterator[StreamItem]:
+        """Yields one ``StreamItem`` per generated token; aborts the request if the consumer goes away."""
+        if self._dead:
+            raise RuntimeError(self._dead)
+        q: asyncio.Queue = asyncio.Queue()
+        self._streams[req_id] = q
+        self._chan.send(("add", req_id, list(map(int, prompt_ids)), dataclasses.asdict(params), time.perf_counter()))
+        finished = False
+        try:
+            while True:
+                item = await q.get()
+                finished = item.finished
+                yield item
+                if finished:
+                    return
+        finally:
+            self._streams.pop(req_id, None)
+            if not finished:
+                self._chan.send(("abort", req_id))
+
+    async def stats(self, timeout: float = 5.0) -> dict:
+        fut = self._loop.create_future()
+        self._stats_waiters.append(fut)
+        self._chan.send(("stats",))
+        return await asyncio.wait_for(fut, timeout)
+
+    @property
+    def num_streams(self) -> int:
+        return len(self._streams)
+
+    async def shutdown(self):
+        try:
+            self._chan.send(("shutdown",))
+        except Exception:
+            pass
+        if self.mode == "thread":
+            self._core.join(timeout=10)
+            self._chan.rx.put(("bye",))
+        else:
+            self._core.join(timeout=20)
+            if self._core.is_alive():
+                self._core.terminate()
