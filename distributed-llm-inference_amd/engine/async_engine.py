@@ -87,7 +87,11 @@ def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
                 break
             busy = True
         if running and engine.has_unfinished():
-            outs = engine.step()
+            try:
+                outs = engine.step()
+            except Exception:                                # a failed step must not strand the clients
+                chan.send(("dead", traceback.format_exc()))
+                raise
             if outs:
                 chan.send(("out", [(o.req_id, o.new_token_ids[0], o.finished, o.finish_reason, o.num_prompt_tokens,
                                     o.num_output_tokens, o.num_cached_tokens) for o in outs]))
@@ -106,6 +110,8 @@ def _process_main(cfg: EngineConfig, conn, device_index: int):
         engine.warmup()
         conn.send(("ready", {"kv_cache_tokens": engine.runner.kv_cache_tokens, "load_seconds": engine.runner.load_seconds}))
         engine_core_loop(engine, conn)
+        from ..runtime.tp_launcher import join_children
+        join_children()
     except Exception:
         conn.send(("dead", traceback.format_exc()))
         raise
@@ -144,7 +150,8 @@ class AsyncEngine:
             ctx = mp.get_context("spawn")
             parent, child = ctx.Pipe(duplex=True)
             self._chan = parent
-            self._core = ctx.Process(target=_process_main, args=(cfg, child, device_index), daemon=True,
+            # not a daemon: under TP the core process spawns the worker ranks itself
+            self._core = ctx.Process(target=_process_main, args=(cfg, child, device_index), daemon=False,
                                      name="engine-core")
             self.engine = None
         else:

@@ -28,6 +28,8 @@ class LLMEngine:
     def __init__(self, cfg: EngineConfig, ctx: Optional[ParallelContext] = None, device=None):
         self.cfg = cfg
         self.ctx = ctx or SINGLE
+        # positions beyond the model's table (RoPE cache / learned positions) do not exist
+        cfg.sched.max_model_len = min(cfg.sched.max_model_len, cfg.model.max_position)
         self.runner = ModelRunner(cfg, self.ctx, device)
         self.tokenizer = get_tokenizer(cfg.model, cfg.tokenizer_path)
         self.metrics = EngineMetrics()

@@ -49,10 +49,12 @@ class ParallelContext:
         """[..., n] on every rank → [..., tp·n] ordered by rank."""
         if self.tp_size == 1:
             return x
-        x = x.contiguous()
-        out = torch.empty((self.tp_size,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x, group=self.group)
-        return out.movedim(0, -2).reshape(*x.shape[:-1], self.tp_size * x.shape[-1])
+        lead, n = x.shape[:-1], x.shape[-1]
+        x2 = x.reshape(-1, n).contiguous()
+        rows = x2.shape[0]
+        out = torch.empty((self.tp_size * rows, n), dtype=x.dtype, device=x.device)   # rank-major concat
+        dist.all_gather_into_tensor(out, x2, group=self.group)
+        return out.view(self.tp_size, rows, n).permute(1, 0, 2).reshape(*lead, self.tp_size * n)
 
     def broadcast_tensor(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
         if self.tp_size > 1:

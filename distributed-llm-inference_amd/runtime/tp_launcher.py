@@ -1,0 +1,85 @@
+"""Tensor-parallel worker processes: one process per GPU, ``torch.distributed`` over RCCL (``nccl``
+backend on ROCm) — gloo on CPU for the tests.
+
+The *driver* (TP rank 0) owns the scheduler, the block manager and the HTTP/engine-core loop; every
+other rank runs ``worker_loop``: receive the step header + packed step buffer broadcast by the
+driver (``ModelRunner._broadcast_step``), execute the same forward pass on its weight shards, take
+part in the all-reduces, sample the same token from the all-gathered logits (same Philox stream), and
+wait for the next step.  SURVEY.md §3.6 "broadcast metadata to TP ranks".
+"""
+from __future__ import annotations
+
+import multiprocessing as mp
+import os
+import socket
+from typing import Optional
+
+import torch
+
+from ..config import EngineConfig
+from ..parallel.state import SINGLE, ParallelContext, init_distributed, make_tp_context
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _device_for(cfg: EngineConfig, rank: int, base_index: int) -> torch.device:
+    use_gpu = cfg.device == "cuda" or (cfg.device == "auto" and torch.cuda.is_available())
+    if use_gpu:
+        torch.cuda.set_device(base_index + rank)
+        return torch.device("cuda", base_index + rank)
+    return torch.device("cpu")
+
+
+def _join_group(cfg: EngineConfig, rank: int, world: int, port: int, base_index: int):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = _device_for(cfg, rank, base_index)
+    init_distributed(cfg.parallel.backend, device)
+    ctx = make_tp_context(world, ep_size=cfg.parallel.ep if cfg.parallel.ep > 1 else 1,
+                          custom_all_reduce=cfg.parallel.custom_all_reduce, device=device)
+    return ctx, device
+
+
+def _worker_main(cfg: EngineConfig, rank: int, world: int, port: int, base_index: int):
+    from ..engine.engine import LLMEngine
+    ctx, device = _join_group(cfg, rank, world, port, base_index)
+    engine = LLMEngine(cfg, ctx, device)
+    engine.warmup()
+    worker_loop(engine)
+
+
+def worker_loop(engine) -> None:
+    while engine.runner.worker_step():
+        pass
+
+
+_children: list = []
+
+
+def maybe_launch_tp(cfg: EngineConfig, base_index: int = 0) -> Optional[ParallelContext]:
+    """In the driver process: spawn ``tp-1`` workers and join the group as rank 0.  Returns the
+    driver's ``ParallelContext`` (``SINGLE`` when tp == 1)."""
+    tp = cfg.parallel.tp
+    if tp <= 1:
+        return SINGLE
+    port = _free_port()
+    spawn = mp.get_context("spawn")
+    for rank in range(1, tp):
+        p = spawn.Process(target=_worker_main, args=(cfg, rank, tp, port, base_index), daemon=True, name=f"tp-worker-{rank}")
+        p.start()
+        _children.append(p)
+    ctx, _device = _join_group(cfg, 0, tp, port, base_index)
+    return ctx
+
+
+def join_children(timeout: float = 20.0):
+    for p in _children:
+        p.join(timeout)
+        if p.is_alive():
+            p.terminate()
+    _children.clear()

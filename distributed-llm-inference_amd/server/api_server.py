@@ -1,0 +1,342 @@
+"""HTTP front end (aiohttp): the first-party replacement of the black-box server the reference
+harness pointed at (`/root/reference/traffic_generator/main.py:306`).
+
+Endpoints
+  POST /api/generate          Ollama wire format — what the harness actually calls.  Streaming body is
+                              ``application/x-ndjson``: one ``{"model","created_at","response","done":false}``
+                              line per token and a final ``done:true`` line with ``done_reason``, ``context``
+                              and the ns duration counters recorded in
+                              `/root/reference/notebooks/aiohttp_tracing.ipynb:192-197`.
+  POST /v1/completions        OpenAI-compatible; SSE (``data: {...}\\n\\n`` … ``data: [DONE]``) when streaming.
+  POST /v1/chat/completions   minimal chat wrapper over the same engine.
+  GET  /api/tags /v1/models /api/version /health /stats /metrics (Prometheus text)
+
+Behavioural notes:
+* top-level ``temperature`` / ``max_tokens`` of the harness payload are honoured (Ollama ignored them);
+  Ollama-style ``options.{temperature,num_predict,top_p,top_k,seed}`` are accepted too;
+* response headers are flushed at admission, *before* the first token exists, so the harness'
+  ``response_headers_received_time`` is a true server acknowledgement time;
+* a client that disconnects mid-stream aborts its request, which frees the KV pages.
+
+    python -m dli_amd.server.api_server --model llama3-8b --port 11434
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import itertools
+import json
+import time
+from datetime import datetime, timezone
+
+from aiohttp import web
+
+from ..config import (CacheConfig, EngineConfig, ParallelConfig, SamplingParams, SchedulerConfig, get_model_config)
+from ..engine.async_engine import AsyncEngine
+from ..engine.tokenizer import get_tokenizer
+
+
+def _now_iso() -> str:
+    return datetime.now(timezone.utc).isoformat().replace("+00:00", "Z")
+
+
+class ApiServer:
+    def __init__(self, cfg: EngineConfig, engine_mode: str = "thread", served_name: str | None = None,
+                 default_max_tokens: int = 128, engine=None):
+        self.cfg = cfg
+        self.aengine = AsyncEngine(cfg, mode=engine_mode, engine=engine)
+        self.tokenizer = get_tokenizer(cfg.model, cfg.tokenizer_path)
+        self.served_name = served_name or cfg.model.name
+        self.default_max_tokens = default_max_tokens
+        self._ids = itertools.count()
+        self.started = time.time()
+
+    # ------------------------------------------------------------------ helpers
+    def _params(self, body: dict) -> SamplingParams:
+        opt = body.get("options") or {}
+
+        def pick(*names, default=None):
+            for n in names:
+                if body.get(n) is not None:
+                    return body[n]
+                if opt.get(n) is not None:
+                    return opt[n]
+            return default
+
+        max_tokens = pick("max_tokens", "num_predict", "max_completion_tokens", default=self.default_max_tokens)
+        if int(max_tokens) <= 0:
+            max_tokens = self.default_max_tokens
+        seed = pick("seed")
+        return SamplingParams(temperature=float(pick("temperature", default=0.8)), top_p=float(pick("top_p", default=1.0)),
+                              top_k=int(pick("top_k", default=0)), max_tokens=int(max_tokens),
+                              ignore_eos=bool(pick("ignore_eos", default=False)),
+                              seed=None if seed is None else int(seed))
+
+    def _rid(self, prefix: str) -> str:
+        return f"{prefix}-{next(self._ids)}"
+
+    @staticmethod
+    def _bad(msg: str, status: int = 400):
+        return web.json_response({"error": msg}, status=status)
+
+    async def _json(self, request):
+        try:
+            body = await request.json()
+            if not isinstance(body, dict):
+                raise ValueError("body must be a JSON object")
+            return body
+        except Exception as e:
+            raise web.HTTPBadRequest(text=json.dumps({"error": f"invalid JSON body: {e}"}),
+                                     content_type="application/json")
+
+    # ------------------------------------------------------------------ Ollama: /api/generate
+    async def api_generate(self, request: web.Request):
+        body = await self._json(request)
+        prompt = body.get("prompt")
+        if not isinstance(prompt, str):
+            return self._bad("'prompt' must be a string")
+        model = body.get("model") or self.served_name
+        stream = body.get("stream", True)
+        params = self._params(body)
+        ids = self.tokenizer.encode(prompt)
+        rid = self._rid("gen")
+        t0 = time.perf_counter_ns()
+        dec = self.tokenizer.stream_decoder()
+        t_first = None
+        out_ids: list[int] = []
+        reason = "stop"
+
+        if stream:
+            resp = web.StreamResponse(headers={"Content-Type": "application/x-ndjson"})
+            await resp.prepare(request)                              # ack now: admission, not first token
+            dumps = json.dumps
+            try:
+                async for item in self.aengine.generate(rid, ids, params):
+                    if item.token is not None:
+                        if t_first is None:
+                            t_first = time.perf_counter_ns()
+                        out_ids.append(item.token)
+                        piece = dec.step(item.token)
+                        await resp.write((dumps({"model": model, "created_at": _now_iso(), "response": piece,
+                                                 "done": False}) + "\n").encode())
+                    if item.finished:
+                        reason = item.reason or "stop"
+                        n_prompt = item.n_prompt
+                t_end = time.perf_counter_ns()
+                tail = self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, dec.flush())
+                await resp.write((dumps(tail) + "\n").encode())
+                await resp.write_eof()
+            except (ConnectionResetError, asyncio.CancelledError):
+                raise                                                # generator's finally aborts the request
+            return resp
+
+        text = []
+        async for item in self.aengine.generate(rid, ids, params):
+            if item.token is not None:
+                if t_first is None:
+                    t_first = time.perf_counter_ns()
+                out_ids.append(item.token)
+                text.append(dec.step(item.token))
+            if item.finished:
+                reason = item.reason or "stop"
+        t_end = time.perf_counter_ns()
+        return web.json_response(self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end,
+                                                   "".join(text) + dec.flush()))
+
+    @staticmethod
+    def _ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, response_text):
+        t_first = t_first or t_end
+        if reason.startswith("error"):
+            return {"model": model, "created_at": _now_iso(), "response": "", "done": True, "done_reason": "error",
+                    "error": reason}
+        return {"model": model, "created_at": _now_iso(), "response": response_text, "done": True,
+                "done_reason": "stop" if reason == "stop" else reason,
+                "context": list(ids) + out_ids, "total_duration": t_end - t0, "load_duration": 0,
+                "prompt_eval_count": len(ids), "prompt_eval_duration": t_first - t0,
+                "eval_count": len(out_ids), "eval_duration": t_end - t_first}
+
+    # ------------------------------------------------------------------ OpenAI: /v1/completions
+    async def v1_completions(self, request: web.Request, chat: bool = False):
+        body = await self._json(request)
+        if chat:
+            msgs = body.get("messages")
+            if not isinstance(msgs, list) or not msgs:
+                return self._bad("'messages' must be a non-empty list")
+            prompt = "".join(f"{m.get('role', 'user')}: {m.get('content', '')}\n" for m in msgs) + "assistant: "
+        else:
+            prompt = body.get("prompt")
+            if isinstance(prompt, list) and prompt and all(isinstance(x, int) for x in prompt):
+                prompt = None
+            elif isinstance(prompt, list) and len(prompt) == 1:
+                prompt = prompt[0]
+            if prompt is not None and not isinstance(prompt, str):
+                return self._bad("'prompt' must be a string or a list of token ids")
+        ids = body["prompt"] if prompt is None else self.tokenizer.encode(prompt)
+        model = body.get("model") or self.served_name
+        params = self._params(body)
+        rid = self._rid("chatcmpl" if chat else "cmpl")
+        created = int(time.time())
+        obj = "chat.completion" if chat else "text_completion"
+        dec = self.tokenizer.stream_decoder()
+
+        def chunk(piece, finish=None, streaming=True):
+            if chat:
+                key = "delta" if streaming else "message"
+                ch = {"index": 0, key: {"role": "assistant", "content": piece}, "finish_reason": finish}
+            else:
+                ch = {"index": 0, "text": piece, "logprobs": None, "finish_reason": finish}
+            return {"id": rid, "object": obj + (".chunk" if chat and streaming else ""), "created": created,
+                    "model": model, "choices": [ch]}
+
+        if body.get("stream"):
+            resp = web.StreamResponse(headers={"Content-Type": "text/event-stream", "Cache-Control": "no-cache"})
+            await resp.prepare(request)
+            n_out = n_prompt = 0
+            async for item in self.aengine.generate(rid, ids, params):
+                finish = None
+                if item.finished:
+                    finish = "length" if item.reason == "length" else (item.reason or "stop")
+                    n_out, n_prompt = item.n_out, item.n_prompt
+                piece = dec.step(item.token) if item.token is not None else ""
+                if item.finished:
+                    piece += dec.flush()
+                await resp.write(("data: " + json.dumps(chunk(piece, finish)) + "\n\n").encode())
+            if (body.get("stream_options") or {}).get("include_usage"):
+                usage = {"id": rid, "object": obj, "created": created, "model": model, "choices": [],
+                         "usage": {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}}
+                await resp.write(("data: " + json.dumps(usage) + "\n\n").encode())
+            await resp.write(b"data: [DONE]\n\n")
+            await resp.write_eof()
+            return resp
+
+        pieces, finish, n_out, n_prompt = [], "stop", 0, len(ids)
+        async for item in self.aengine.generate(rid, ids, params):
+            if item.token is not None:
+                pieces.append(dec.step(item.token))
+            if item.finished:
+                finish = "length" if item.reason == "length" else (item.reason or "stop")
+                n_out, n_prompt = item.n_out, item.n_prompt
+        out = chunk("".join(pieces) + dec.flush(), finish, streaming=False)
+        out["usage"] = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
+        return web.json_response(out)
+
+    async def v1_chat(self, request):
+        return await self.v1_completions(request, chat=True)
+
+    # ------------------------------------------------------------------ introspection
+    async def health(self, request):
+        return web.json_response({"status": "ok", "model": self.served_name, "uptime_s": time.time() - self.started,
+                                  "streams": self.aengine.num_streams})
+
+    async def stats(self, request):
+        s = await self.aengine.stats()
+        s.pop("prometheus", None)
+        s["streams"] = self.aengine.num_streams
+        return web.json_response(s)
+
+    async def metrics(self, request):
+        s = await self.aengine.stats()
+        return web.Response(text=s["prometheus"], content_type="text/plain")
+
+    async def tags(self, request):
+        m = self.cfg.model
+        return web.json_response({"models": [{"name": self.served_name, "model": self.served_name,
+                                              "details": {"family": m.arch, "parameter_size": f"{m.param_count() / 1e9:.1f}B",
+                                                          "quantization_level": m.dtype}}]})
+
+    async def models(self, request):
+        return web.json_response({"object": "list", "data": [{"id": self.served_name, "object": "model",
+                                                              "created": int(self.started), "owned_by": "dli_amd"}]})
+
+    async def version(self, request):
+        from .. import __version__
+        return web.json_response({"version": __version__})
+
+    # ------------------------------------------------------------------ wiring
+    def app(self) -> web.Application:
+        app = web.Application(client_max_size=64 << 20)
+        r = app.router
+        r.add_post("/api/generate", self.api_generate)
+        r.add_post("/v1/completions", self.v1_completions)
+        r.add_post("/v1/chat/completions", self.v1_chat)
+        r.add_get("/health", self.health)
+        r.add_get("/stats", self.stats)
+        r.add_get("/metrics", self.metrics)
+        r.add_get("/api/tags", self.tags)
+        r.add_get("/v1/models", self.models)
+        r.add_get("/api/version", self.version)
+
+        async def on_startup(_app):
+            await self.aengine.start()
+
+        async def on_cleanup(_app):
+            await self.aengine.shutdown()
+
+        app.on_startup.append(on_startup)
+        app.on_cleanup.append(on_cleanup)
+        return app
+
+
+async def start_server(server: ApiServer, host: str = "127.0.0.1", port: int = 0):
+    """Programmatic start (tests, router): returns ``(runner, base_url)``."""
+    runner = web.AppRunner(server.app(), access_log=None)
+    await runner.setup()
+    site = web.TCPSite(runner, host, port, backlog=4096)
+    await site.start()
+    real_port = site._server.sockets[0].getsockname()[1]
+    return runner, f"http://{host}:{real_port}"
+
+
+def engine_config_from_args(a) -> EngineConfig:
+    overrides = {}
+    if a.max_position:
+        overrides["max_position"] = a.max_position
+    return EngineConfig(
+        model=get_model_config(a.model, **overrides),
+        cache=CacheConfig(kv_dtype=a.kv_dtype, num_blocks=a.num_kv_blocks, gpu_memory_utilization=a.gpu_memory_utilization,
+                          enable_prefix_caching=not a.no_prefix_caching),
+        sched=SchedulerConfig(max_num_seqs=a.max_num_seqs, max_num_batched_tokens=a.max_num_batched_tokens,
+                              max_model_len=a.max_model_len, long_prefill_chunk=a.prefill_chunk),
+        parallel=ParallelConfig(tp=a.tp, ep=a.ep, custom_all_reduce=not a.no_custom_all_reduce),
+        device=a.device, seed=a.seed, use_hip_graphs=not a.no_hip_graphs, weights_path=a.weights,
+        tokenizer_path=a.tokenizer)
+
+
+def add_engine_args(ap: argparse.ArgumentParser):
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--weights", default=None, help="safetensors file/dir (default: random init)")
+    ap.add_argument("--tokenizer", default=None, help="HF tokenizer.json (default: byte-level)")
+    ap.add_argument("--device", default="auto", choices=["auto", "cuda", "cpu"])
+    ap.add_argument("--tp", type=int, default=1)
+    ap.add_argument("--ep", type=int, default=1)
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"])
+    ap.add_argument("--num-kv-blocks", type=int, default=None)
+    ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
+    ap.add_argument("--no-prefix-caching", action="store_true")
+    ap.add_argument("--max-num-seqs", type=int, default=512)
+    ap.add_argument("--max-num-batched-tokens", type=int, default=4096)
+    ap.add_argument("--max-model-len", type=int, default=4096)
+    ap.add_argument("--max-position", type=int, default=None)
+    ap.add_argument("--prefill-chunk", type=int, default=2048)
+    ap.add_argument("--no-hip-graphs", action="store_true")
+    ap.add_argument("--no-custom-all-reduce", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="dli_amd inference server")
+    add_engine_args(ap)
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=11434)
+    ap.add_argument("--served-model-name", default=None)
+    ap.add_argument("--engine-mode", default="process", choices=["process", "thread"])
+    ap.add_argument("--default-max-tokens", type=int, default=128)
+    a = ap.parse_args(argv)
+    cfg = engine_config_from_args(a)
+    server = ApiServer(cfg, engine_mode=a.engine_mode, served_name=a.served_model_name,
+                       default_max_tokens=a.default_max_tokens)
+    web.run_app(server.app(), host=a.host, port=a.port, access_log=None, backlog=4096)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""HTTP server tests on CPU (tiny models) + the end-to-end plumbing run of BASELINE.json config 1:
+the preserved harness replays ``data/trace1.csv`` against the first-party server and must produce a
+``log.json`` with the reference schema."""
+import asyncio
+import json
+import os
+import re
+
+import aiohttp
+import pytest
+
+import main as tg
+import analyze
+from dli_amd.config import CacheConfig, EngineConfig, SchedulerConfig, get_model_config
+from dli_amd.server.api_server import ApiServer, start_server
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_server(model="tiny-opt", mode="thread", **kw):
+    cfg = EngineConfig(model=get_model_config(model, max_position=2048), cache=CacheConfig(num_blocks=256),
+                       sched=SchedulerConfig(max_num_seqs=16, max_num_batched_tokens=256, max_model_len=1536,
+                                             long_prefill_chunk=128),
+                       device="cpu", use_hip_graphs=False)
+    return ApiServer(cfg, engine_mode=mode, **kw)
+
+
+def with_server(coro_fn, **kw):
+    async def go():
+        server = make_server(**kw)
+        runner, base = await start_server(server)
+        try:
+            return await coro_fn(server, base)
+        finally:
+            await runner.cleanup()
+    return asyncio.run(go())
+
+
+def test_api_generate_stream_ndjson_wire_format():
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            payload = {"model": "mistral", "prompt": "hello world", "temperature": 0.7, "max_tokens": 7, "stream": True}
+            async with s.post(base + "/api/generate", json=payload) as r:
+                assert r.status == 200 and r.headers["Content-Type"].startswith("application/x-ndjson")
+                assert r.headers.get("Transfer-Encoding") == "chunked"
+                lines = [json.loads(l) async for l in r.content]
+        return lines
+    lines = with_server(body)
+    assert len(lines) == 8                                            # max_tokens honoured + done line
+    for l in lines[:-1]:
+        assert list(l.keys()) == ["model", "created_at", "response", "done"] and l["done"] is False and l["model"] == "mistral"
+    tail = lines[-1]
+    assert tail["done"] is True and tail["done_reason"] in ("stop", "length") and tail["eval_count"] == 7
+    assert tail["prompt_eval_count"] == len("hello world") + 1 and len(tail["context"]) == tail["prompt_eval_count"] + 7
+    for k in ("total_duration", "load_duration", "prompt_eval_duration", "eval_duration"):
+        assert isinstance(tail[k], int)
+    assert re.match(r"\d{4}-\d\d-\d\dT\d\d:\d\d:\d\d", tail["created_at"])
+
+
+def test_api_generate_non_stream_and_options_and_seed():
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            p = {"prompt": "abc", "stream": False, "options": {"num_predict": 5, "temperature": 0.9, "seed": 3, "top_k": 20}}
+            a = await (await s.post(base + "/api/generate", json=p)).json()
+            b = await (await s.post(base + "/api/generate", json=p)).json()
+            bad = await s.post(base + "/api/generate", json={"prompt": 5})
+            bad2 = await s.post(base + "/api/generate", data=b"not json")
+            return a, b, bad.status, bad2.status
+    a, b, st, st2 = with_server(body)
+    assert a["done"] and a["eval_count"] == 5 and a["response"] == b["response"] and a["context"] == b["context"]
+    assert st == 400 and st2 == 400
+
+
+def test_openai_completions_sse_and_usage_and_chat():
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            p = {"model": "m", "prompt": "hi there", "max_tokens": 4, "temperature": 0, "stream": True,
+                 "stream_options": {"include_usage": True}}
+            async with s.post(base + "/v1/completions", json=p) as r:
+                assert r.headers["Content-Type"].startswith("text/event-stream")
+                raw = (await r.read()).decode()
+            ns = await (await s.post(base + "/v1/completions", json={"prompt": "hi there", "max_tokens": 4, "temperature": 0})).json()
+            chat = await (await s.post(base + "/v1/chat/completions",
+                                       json={"messages": [{"role": "user", "content": "yo"}], "max_tokens": 3})).json()
+            models = await (await s.get(base + "/v1/models")).json()
+            tags = await (await s.get(base + "/api/tags")).json()
+            return raw, ns, chat, models, tags
+    raw, ns, chat, models, tags = with_server(body)
+    events = [e for e in raw.split("\n\n") if e]
+    assert events[-1] == "data: [DONE]" and all(e.startswith("data: ") for e in events)
+    chunks = [json.loads(e[6:]) for e in events[:-1]]
+    assert len(chunks) == 5 and chunks[-1]["usage"]["completion_tokens"] == 4
+    assert chunks[3]["choices"][0]["finish_reason"] == "length" and chunks[0]["choices"][0]["finish_reason"] is None
+    assert "".join(c["choices"][0]["text"] for c in chunks[:4]) == ns["choices"][0]["text"]      # greedy: same text
+    assert ns["usage"] == {"prompt_tokens": 9, "completion_tokens": 4, "total_tokens": 13}
+    assert chat["choices"][0]["message"]["role"] == "assistant" and chat["usage"]["completion_tokens"] == 3
+    assert models["data"][0]["id"] == "tiny-opt" and tags["models"][0]["name"] == "tiny-opt"
+
+
+def test_metrics_health_and_abort_on_disconnect():
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            # start a long generation and drop the connection after the first line
+            r = await s.post(base + "/api/generate", json={"prompt": "x" * 200, "max_tokens": 400, "ignore_eos": True})
+            await r.content.readline()
+            r.close()
+            await asyncio.sleep(0.3)
+            for _ in range(50):
+                st = await (await s.get(base + "/stats")).json()
+                if st["num_running"] == 0 and st["num_waiting"] == 0:
+                    break
+                await asyncio.sleep(0.05)
+            await (await s.post(base + "/api/generate", json={"prompt": "ok", "max_tokens": 2, "stream": False})).json()
+            health = await (await s.get(base + "/health")).json()
+            prom = await (await s.get(base + "/metrics")).text()
+            st = await (await s.get(base + "/stats")).json()
+            return st, health, prom
+    st, health, prom = with_server(body)
+    assert st["requests_aborted"] == 1 and st["num_running"] == 0 and st["kv_used_frac"] < 0.05
+    assert health["status"] == "ok"
+    assert "dli_requests_total 2" in prom and "dli_time_to_first_token_seconds_bucket" in prom and "dli_kv_cache_usage" in prom
+
+
+@pytest.mark.parametrize("mode", ["thread", "process"])
+def test_harness_replay_trace1_against_first_party_server(tmp_path, mode):
+    """BASELINE.json config 1 (with a tiny OPT so it runs in seconds)."""
+    import synth
+    pool_path = tmp_path / "conversations.json"
+    synth.make_conversations(str(pool_path), n=150, seed=4)
+    data = tg.DataLoader().get_data_from_path(str(pool_path))
+    sched = tg.Scheduler().get_schedule_from_trace(os.path.join(ROOT, "data", "trace1.csv"), 100)
+    sched["Timestamp"] = sched["Timestamp"] * 0.05
+
+    async def body(server, base):
+        cfg = dict(tg.config, url=base + "/api/generate", max_tokens=12)
+        logger = tg.MetricCollector()
+        gen = tg.TrafficGenerator(data, sched, cfg, logger)
+        await gen.issue_queries()
+        return logger
+
+    logger = with_server(body, mode=mode)
+    m = logger.metrics
+    assert len(m) == 6 and all(e["success"] for e in m.values())
+    keys = ["number_of_input_tokens", "request_start_time", "response_headers_received_time",
+            "first_token_arrive_time", "response_end_time", "scheduled_start_time", "success"]
+    assert all(list(e.keys()) == keys for e in m.values())
+    # headers are acknowledged at admission, before the first token exists
+    assert all(e["response_headers_received_time"] <= e["first_token_arrive_time"] for e in m.values())
+    path = tmp_path / "log.json"
+    logger.save(str(path))
+    num = r"-?\d+(?:\.\d+)?(?:e-?\d+)?"
+    ref = "/root/reference/logs/log.json"
+    if os.path.exists(ref):
+        assert re.sub(num, "N", path.read_text()) == re.sub(num, "N", open(ref).read())
+    n_out = analyze.n_out_from_sidecar({str(k): v for k, v in logger.sidecar.items()})
+    assert set(n_out.values()) == {12}                                # 12 token lines + done line
+    s = analyze.summarize(json.loads(path.read_text()), n_out, slo_ttft=5.0, slo_tpot=1.0)
+    assert s["success"] == 6 and s["slo_attainment"] == 1.0 and s["tpot"]["p50"] is not None
+    # continuous batching: the six requests overlap instead of queueing one behind the other
+    ends = sorted(e["response_end_time"] for e in m.values())
+    starts = sorted(e["first_token_arrive_time"] for e in m.values())
+    assert starts[-1] < ends[0] + 5.0
