@@ -1,0 +1,340 @@
+"""Data-parallel request router (BASELINE.json config 3: "Llama-3 8B DP=8 replicas
+behind request router, conversations.json multi-turn replay").
+
+A streaming reverse proxy in front of N independent engine replicas (one process per GPU, each a
+full ``api_server``).  The harness keeps talking to ONE url; the router picks a replica per request:
+
+* **least outstanding tokens** – every in-flight request is charged ``prompt tokens + max_tokens``
+  (released as it completes), so a replica digesting a burst of long prompts is avoided even if its
+  request count is low;
+* **prefix / session affinity** – the prompt is cut into 256-character blocks with chained hashes;
+  the replica that most recently served the longest matching chain holds those KV pages in its prefix
+  cache (multi-turn prompts extend the previous turn), so the request goes there unless that replica
+  is overloaded relative to the least-loaded one (``affinity_slack``).  ``X-Session-Id`` pins a
+  session the same way;
+* **health** – a background probe marks replicas down after consecutive failures and routes around
+  them; a request that fails before any byte was relayed is retried on another replica.
+
+The wire format is relayed untouched (NDJSON or SSE lines are forwarded as they arrive), so
+``log.json`` semantics are identical with or without the router.
+
+    python -m dli_amd.router.router --replicas http://127.0.0.1:8001,http://127.0.0.1:8002 --port 11434
+    python -m dli_amd.router.router --spawn 8 --model llama3-8b --port 11434      # one replica per GPU
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import json
+import os
+import subprocess
+import sys
+import time
+import zlib
+from collections import OrderedDict
+from typing import Optional
+
+import aiohttp
+from aiohttp import web
+
+BLOCK_CHARS = 256
+MAX_BLOCKS = 64
+
+
+def prefix_chain(prompt: str) -> list[int]:
+    """Chained hashes of the 256-character blocks of ``prompt`` (whole blocks only)."""
+    out, h = [], 0
+    data = prompt.encode("utf-8", "ignore")
+    for i in range(min(len(data) // BLOCK_CHARS, MAX_BLOCKS)):
+        h = zlib.crc32(data[i * BLOCK_CHARS:(i + 1) * BLOCK_CHARS], h) ^ (i * 0x9E3779B1 & 0xFFFFFFFF)
+        out.append((h << 8) | (i & 0xFF))
+    return out
+
+
+class Replica:
+    def __init__(self, url: str):
+        self.url = url.rstrip("/")
+        self.outstanding_tokens = 0
+        self.inflight = 0
+        self.healthy = True
+        self.fails = 0
+        self.served = 0
+        self.errors = 0
+
+    def load(self) -> float:
+        return self.outstanding_tokens + 64 * self.inflight
+
+
+class RoutingPolicy:
+    """Pure decision logic (unit-testable without sockets)."""
+
+    def __init__(self, replicas: list[Replica], affinity_slack: float = 0.5, slack_tokens: int = 4096,
+                 table_size: int = 200_000):
+        self.replicas = replicas
+        self.affinity_slack = affinity_slack
+        self.slack_tokens = slack_tokens
+        self.table: OrderedDict[int, int] = OrderedDict()      # prefix-chain hash / session key → replica index
+        self.table_size = table_size
+        self.affinity_hits = 0
+        self.decisions = 0
+
+    def _remember(self, key: int, idx: int):
+        self.table[key] = idx
+        self.table.move_to_end(key)
+        while len(self.table) > self.table_size:
+            self.table.popitem(last=False)
+
+    def choose(self, chain: list[int], session: Optional[str] = None, exclude: frozenset = frozenset()) -> Optional[int]:
+        alive = [i for i, r in enumerate(self.replicas) if r.healthy and i not in exclude]
+        if not alive:
+            return None
+        self.decisions += 1
+        best = min(alive, key=lambda i: (self.replicas[i].load(), i))
+        cand = None
+        if session is not None:
+            cand = self.table.get(zlib.crc32(session.encode()) | (1 << 60))
+        if cand is None:
+            for key in reversed(chain):                             # longest cached prefix first
+                cand = self.table.get(key)
+                if cand is not None:
+                    break
+        if cand is not None and cand in alive:
+            lb, lc = self.replicas[best].load(), self.replicas[cand].load()
+            if lc <= lb * (1.0 + self.affinity_slack) + self.slack_tokens:
+                self.affinity_hits += 1
+                best = cand
+        return best
+
+    def record(self, idx: int, chain: list[int], session: Optional[str] = None):
+        for key in chain:
+            self._remember(key, idx)
+        if session is not None:
+            self._remember(zlib.crc32(session.encode()) | (1 << 60), idx)
+
+
+class Router:
+    def __init__(self, replica_urls: list[str], health_interval: float = 2.0, max_fails: int = 2, retries: int = 2,
+                 chars_per_token: float = 1.0, **policy_kw):
+        self.replicas = [Replica(u) for u in replica_urls]
+        self.policy = RoutingPolicy(self.replicas, **policy_kw)
+        self.health_interval = health_interval
+        self.max_fails = max_fails
+        self.retries = retries
+        self.chars_per_token = chars_per_token
+        self.session: Optional[aiohttp.ClientSession] = None
+        self._health_task = None
+        self.started = time.time()
+
+    # ------------------------------------------------------------------ lifecycle
+    async def start(self):
+        conn = aiohttp.TCPConnector(limit=0, keepalive_timeout=30)
+        self.session = aiohttp.ClientSession(connector=conn, timeout=aiohttp.ClientTimeout(total=None, sock_connect=5))
+        self._health_task = asyncio.create_task(self._health_loop())
+
+    async def stop(self):
+        if self._health_task:
+            self._health_task.cancel()
+        if self.session:
+            await self.session.close()
+
+    async def _probe(self, r: Replica):
+        try:
+            async with self.session.get(r.url + "/health", timeout=aiohttp.ClientTimeout(total=2)) as resp:
+                ok = resp.status == 200
+        except Exception:
+            ok = False
+        if ok:
+            r.fails, r.healthy = 0, True
+        else:
+            r.fails += 1
+            if r.fails >= self.max_fails:
+                r.healthy = False
+
+    async def _health_loop(self):
+        while True:
+            await asyncio.gather(*(self._probe(r) for r in self.replicas))
+            await asyncio.sleep(self.health_interval)
+
+    # ------------------------------------------------------------------ proxying
+    def _cost(self, body: dict) -> int:
+        prompt = body.get("prompt")
+        if prompt is None and isinstance(body.get("messages"), list):
+            prompt = "".join(str(m.get("content", "")) for m in body["messages"])
+        n_prompt = int(len(prompt) / self.chars_per_token) if isinstance(prompt, str) else len(prompt or ())
+        opt = body.get("options") or {}
+        max_tokens = body.get("max_tokens") or opt.get("num_predict") or 128
+        return n_prompt + int(max_tokens)
+
+    async def proxy(self, request: web.Request):
+        raw = await request.read()
+        try:
+            body = json.loads(raw)
+            assert isinstance(body, dict)
+        except Exception:
+            return web.json_response({"error": "invalid JSON body"}, status=400)
+        prompt = body.get("prompt") if isinstance(body.get("prompt"), str) else \
+            "".join(str(m.get("content", "")) for m in body.get("messages", []) if isinstance(m, dict))
+        chain = prefix_chain(prompt)
+        session_id = request.headers.get("X-Session-Id")
+        cost = self._cost(body)
+        tried: set[int] = set()
+        for _attempt in range(self.retries + 1):
+            idx = self.policy.choose(chain, session_id, frozenset(tried))
+            if idx is None:
+                break
+            tried.add(idx)
+            rep = self.replicas[idx]
+            rep.outstanding_tokens += cost
+            rep.inflight += 1
+            resp: Optional[web.StreamResponse] = None
+            try:
+                async with self.session.post(rep.url + request.path, data=raw,
+                                             headers={"Content-Type": "application/json"}) as up:
+                    resp = web.StreamResponse(status=up.status,
+                                              headers={"Content-Type": up.headers.get("Content-Type", "application/json"),
+                                                       "X-Served-By": str(idx)})
+                    await resp.prepare(request)
+                    self.policy.record(idx, chain, session_id)
+                    async for chunk in up.content.iter_any():
+                        await resp.write(chunk)
+                    await resp.write_eof()
+                    rep.served += 1
+                    return resp
+            except (aiohttp.ClientConnectionError, asyncio.TimeoutError, aiohttp.ClientPayloadError) as e:
+                rep.errors += 1
+                rep.fails += 1
+                if rep.fails >= self.max_fails:
+                    rep.healthy = False
+                if resp is not None:                                 # bytes already relayed: cannot retry —
+                    if request.transport is not None:                #   break the client stream so it sees a failure
+                        request.transport.close()
+                    return resp
+            finally:
+                rep.outstanding_tokens -= cost
+                rep.inflight -= 1
+        return web.json_response({"error": "no healthy replica"}, status=503)
+
+    # ------------------------------------------------------------------ introspection
+    async def health(self, request):
+        up = sum(r.healthy for r in self.replicas)
+        return web.json_response({"status": "ok" if up else "down", "replicas_up": up, "replicas": len(self.replicas)},
+                                 status=200 if up else 503)
+
+    def stats_dict(self) -> dict:
+        return {"decisions": self.policy.decisions, "affinity_hits": self.policy.affinity_hits,
+                "replicas": [{"url": r.url, "healthy": r.healthy, "inflight": r.inflight,
+                              "outstanding_tokens": r.outstanding_tokens, "served": r.served, "errors": r.errors}
+                             for r in self.replicas]}
+
+    async def stats(self, request):
+        return web.json_response(self.stats_dict())
+
+    async def metrics(self, request):
+        """Router gauges + every replica's Prometheus text, labelled by replica index."""
+        lines = ["# TYPE dli_router_decisions_total counter", f"dli_router_decisions_total {self.policy.decisions}",
+                 "# TYPE dli_router_affinity_hits_total counter", f"dli_router_affinity_hits_total {self.policy.affinity_hits}"]
+        for i, r in enumerate(self.replicas):
+            lines.append(f'dli_router_replica_healthy{{replica="{i}"}} {int(r.healthy)}')
+            lines.append(f'dli_router_replica_outstanding_tokens{{replica="{i}"}} {r.outstanding_tokens}')
+            lines.append(f'dli_router_replica_inflight{{replica="{i}"}} {r.inflight}')
+
+        async def grab(i, r):
+            try:
+                async with self.session.get(r.url + "/metrics", timeout=aiohttp.ClientTimeout(total=3)) as resp:
+                    txt = await resp.text()
+            except Exception:
+                return []
+            out = []
+            for ln in txt.splitlines():
+                if ln.startswith("#") or not ln.strip():
+                    continue
+                name, _, val = ln.rpartition(" ")
+                out.append(f'{name[:-1]},replica="{i}"}} {val}' if name.endswith("}") else f'{name}{{replica="{i}"}} {val}')
+            return out
+        for part in await asyncio.gather(*(grab(i, r) for i, r in enumerate(self.replicas) if r.healthy)):
+            lines += part
+        return web.Response(text="\n".join(lines) + "\n", content_type="text/plain")
+
+    def app(self) -> web.Application:
+        app = web.Application(client_max_size=64 << 20)
+        for path in ("/api/generate", "/v1/completions", "/v1/chat/completions"):
+            app.router.add_post(path, self.proxy)
+        app.router.add_get("/health", self.health)
+        app.router.add_get("/router/stats", self.stats)
+        app.router.add_get("/metrics", self.metrics)
+
+        async def on_startup(_):
+            await self.start()
+
+        async def on_cleanup(_):
+            await self.stop()
+        app.on_startup.append(on_startup)
+        app.on_cleanup.append(on_cleanup)
+        return app
+
+
+async def start_router(router: Router, host: str = "127.0.0.1", port: int = 0):
+    runner = web.AppRunner(router.app(), access_log=None)
+    await runner.setup()
+    site = web.TCPSite(runner, host, port, backlog=4096)
+    await site.start()
+    return runner, f"http://{host}:{site._server.sockets[0].getsockname()[1]}"
+
+
+def spawn_replicas(n: int, base_port: int, server_args: list[str], gpus: bool = True) -> list[subprocess.Popen]:
+    """One ``api_server`` process per GPU (``HIP_VISIBLE_DEVICES=i``), ports ``base_port + i``."""
+    procs = []
+    for i in range(n):
+        env = dict(os.environ)
+        if gpus:
+            env["HIP_VISIBLE_DEVICES"] = str(i)
+        cmd = [sys.executable, "-m", "dli_amd.server.api_server", "--host", "127.0.0.1", "--port", str(base_port + i)] + server_args
+        procs.append(subprocess.Popen(cmd, env=env))
+    return procs
+
+
+async def wait_ready(urls: list[str], timeout: float = 1800.0):
+    t0 = time.time()
+    async with aiohttp.ClientSession() as s:
+        for u in urls:
+            while True:
+                try:
+                    async with s.get(u + "/health", timeout=aiohttp.ClientTimeout(total=2)) as r:
+                        if r.status == 200:
+                            break
+                except Exception:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"replica {u} did not come up")
+                await asyncio.sleep(0.5)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="dli_amd data-parallel router")
+    ap.add_argument("--replicas", default="", help="comma-separated replica base URLs")
+    ap.add_argument("--spawn", type=int, default=0, help="spawn this many replicas (one per GPU) instead")
+    ap.add_argument("--replica-base-port", type=int, default=18000)
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=11434)
+    ap.add_argument("--affinity-slack", type=float, default=0.5)
+    ap.add_argument("--cpu", action="store_true", help="spawned replicas run on CPU (plumbing tests)")
+    a, server_args = ap.parse_known_args(argv)
+    procs = []
+    if a.spawn:
+        urls = [f"http://127.0.0.1:{a.replica_base_port + i}" for i in range(a.spawn)]
+        procs = spawn_replicas(a.spawn, a.replica_base_port, server_args, gpus=not a.cpu)
+        asyncio.run(wait_ready(urls))
+    else:
+        urls = [u for u in a.replicas.split(",") if u]
+    if not urls:
+        ap.error("give --replicas or --spawn")
+    router = Router(urls, affinity_slack=a.affinity_slack)
+    try:
+        web.run_app(router.app(), host=a.host, port=a.port, access_log=None, backlog=4096)
+    finally:
+        for p in procs:
+            p.terminate()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""DP router tests: policy unit tests + an integration run with two CPU replicas (SURVEY.md §4 item 5:
+"router tests can spawn N CPU replicas")."""
+import asyncio
+import json
+
+import aiohttp
+
+from dli_amd.config import CacheConfig, EngineConfig, SchedulerConfig, get_model_config
+from dli_amd.router.router import Replica, Router, RoutingPolicy, prefix_chain, start_router
+from dli_amd.server.api_server import ApiServer, start_server
+
+
+def test_prefix_chain_is_prefix_stable():
+    a = "s" * 300 + "x" * 600
+    b = a + "more text " * 80
+    ca, cb = prefix_chain(a), prefix_chain(b)
+    assert len(ca) == 3 and cb[:3] == ca and len(cb) > 3
+    assert prefix_chain("short") == []
+    assert prefix_chain("t" * 300)[0] != ca[0]
+
+
+def test_policy_least_outstanding_tokens_and_affinity():
+    reps = [Replica(f"http://r{i}") for i in range(3)]
+    pol = RoutingPolicy(reps, affinity_slack=0.5, slack_tokens=100)
+    reps[0].outstanding_tokens, reps[1].outstanding_tokens, reps[2].outstanding_tokens = 5000, 100, 3000
+    assert pol.choose([]) == 1
+    chain = prefix_chain("p" * 1000)
+    pol.record(2, chain)
+    reps[2].outstanding_tokens = 200                     # within slack of the best → affinity wins
+    assert pol.choose(chain + [123]) == 2
+    reps[2].outstanding_tokens = 50_000                  # overloaded → fall back to least loaded
+    assert pol.choose(chain) == 1
+    reps[1].healthy = False
+    assert pol.choose([]) == 0
+    assert pol.choose([], exclude=frozenset({0})) == 2
+    pol.record(0, [], session="abc")
+    reps[0].outstanding_tokens = 0
+    assert pol.choose([], session="abc") == 0
+    for r in reps:
+        r.healthy = False
+    assert pol.choose([]) is None
+
+
+def _server():
+    cfg = EngineConfig(model=get_model_config("tiny-opt", max_position=2048), cache=CacheConfig(num_blocks=256),
+                       sched=SchedulerConfig(max_num_seqs=16, max_num_batched_tokens=256, max_model_len=1536),
+                       device="cpu", use_hip_graphs=False)
+    return ApiServer(cfg, engine_mode="thread")
+
+
+def test_router_end_to_end_two_replicas_affinity_and_failover():
+    async def go():
+        s1, s2 = _server(), _server()
+        r1, u1 = await start_server(s1)
+        r2, u2 = await start_server(s2)
+        router = Router([u1, u2], health_interval=0.2, max_fails=1)
+        rr, base = await start_router(router)
+        try:
+            async with aiohttp.ClientSession() as s:
+                async def gen(prompt, **kw):
+                    async with s.post(base + "/api/generate", json={"prompt": prompt, "max_tokens": 4, **kw}) as r:
+                        lines = [json.loads(l) async for l in r.content]
+                        return r.status, r.headers.get("X-Served-By"), lines
+                # concurrent distinct prompts spread over both replicas
+                res = await asyncio.gather(*(gen(f"{i} " + "q" * 40) for i in range(8)))
+                assert all(st == 200 and len(l) == 5 and l[-1]["done"] for st, _, l in res)
+                assert {by for _, by, _ in res} == {"0", "1"}
+                # multi-turn: the second turn extends the first → same replica, prefix cache hit there
+                turn1 = "system: be brief.\n" + "user: " + "w" * 600
+                _, by1, l1 = await gen(turn1)
+                turn2 = turn1 + "".join(x["response"] for x in l1) + "\nuser: and then?"
+                _, by2, _ = await gen(turn2)
+                assert by1 == by2
+                stats = [await (await s.get(u + "/stats")).json() for u in (u1, u2)]
+                assert stats[int(by1)]["cached_prompt_tokens"] >= 512
+                # OpenAI path is proxied too
+                async with s.post(base + "/v1/completions", json={"prompt": "hi", "max_tokens": 2}) as r:
+                    assert r.status == 200 and (await r.json())["usage"]["completion_tokens"] == 2
+                # failover: kill replica 0; requests keep succeeding on replica 1
+                await r1.cleanup()
+                res = await asyncio.gather(*(gen(f"after {i}") for i in range(6)))
+                assert all(st == 200 and by == "1" for st, by, _ in res)
+                h = await (await s.get(base + "/health")).json()
+                assert h["replicas_up"] == 1
+                rs = await (await s.get(base + "/router/stats")).json()
+                assert rs["replicas"][0]["healthy"] is False and rs["affinity_hits"] >= 1
+                prom = await (await s.get(base + "/metrics")).text()
+                assert 'dli_router_replica_healthy{replica="0"} 0' in prom and 'dli_requests_total{replica="1"}' in prom
+        finally:
+            await rr.cleanup()
+            await r2.cleanup()
+    asyncio.run(go())
