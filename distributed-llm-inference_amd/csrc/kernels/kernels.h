@@ -30,4 +30,15 @@ void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int
                    const float* top_p, const int* top_k, const int64_t* seeds, const int64_t* steps, const float* noise,
                    int64_t* out, hipStream_t stream);
 
+// custom all-reduce over IPC-mapped peer buffers (custom_all_reduce.hip)
+void* ar_alloc(size_t bytes, bool uncached);
+void ar_free(void* p);
+int ar_ipc_handle(void* p, void* handle_out64);
+void* ar_ipc_open(const void* handle64);
+size_t ar_signal_bytes();
+void* ar_create(int rank, int world, const int64_t* staging, const int64_t* result, const int64_t* signal, size_t max_bytes);
+void ar_destroy(void* st);
+int ar_error(void* st);
+int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, hipStream_t stream);
+
 }  // namespace dli

@@ -160,9 +160,57 @@ void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const T
                      steps.data_ptr<int64_t>(), nz, out.data_ptr<int64_t>(), cur_stream(logits));
 }
 
+// ---- custom all-reduce: raw allocations + IPC handles travel as int64 / uint8 tensors -------------
+int64_t ar_alloc(int64_t bytes, bool uncached) {
+  void* p = dli::ar_alloc((size_t)bytes, uncached);
+  TORCH_CHECK(p != nullptr, "ar_alloc: hipMalloc of ", bytes, " bytes failed");
+  return reinterpret_cast<int64_t>(p);
+}
+void ar_free(int64_t ptr) { dli::ar_free(reinterpret_cast<void*>(ptr)); }
+Tensor ar_ipc_handle(int64_t ptr) {
+  Tensor h = at::zeros({64}, at::TensorOptions().dtype(at::kByte));
+  const int rc = dli::ar_ipc_handle(reinterpret_cast<void*>(ptr), h.data_ptr());
+  TORCH_CHECK(rc == 0, "hipIpcGetMemHandle failed with code ", rc, " (is HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+  return h;
+}
+int64_t ar_ipc_open(const Tensor& handle) {
+  TORCH_CHECK(!handle.is_cuda() && handle.scalar_type() == at::kByte && handle.numel() == 64 && handle.is_contiguous());
+  void* p = dli::ar_ipc_open(handle.data_ptr());
+  TORCH_CHECK(p != nullptr, "hipIpcOpenMemHandle failed");
+  return reinterpret_cast<int64_t>(p);
+}
+int64_t ar_signal_bytes() { return (int64_t)dli::ar_signal_bytes(); }
+int64_t ar_create(int64_t rank, int64_t world, const Tensor& staging, const Tensor& result, const Tensor& signal, int64_t max_bytes) {
+  for (const Tensor* t : {&staging, &result, &signal})
+    TORCH_CHECK(!t->is_cuda() && t->scalar_type() == at::kLong && t->numel() == world && t->is_contiguous());
+  void* st = dli::ar_create((int)rank, (int)world, staging.data_ptr<int64_t>(), result.data_ptr<int64_t>(),
+                            signal.data_ptr<int64_t>(), (size_t)max_bytes);
+  TORCH_CHECK(st != nullptr, "ar_create: world size not supported");
+  return reinterpret_cast<int64_t>(st);
+}
+void ar_destroy(int64_t st) { dli::ar_destroy(reinterpret_cast<void*>(st)); }
+int64_t ar_error(int64_t st) { return dli::ar_error(reinterpret_cast<void*>(st)); }
+void ar_all_reduce(int64_t st, const Tensor& inp, Tensor out, int64_t algo) {
+  TORCH_CHECK(inp.is_cuda() && out.is_cuda() && inp.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16);
+  TORCH_CHECK(inp.is_contiguous() && out.is_contiguous() && inp.numel() == out.numel());
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(inp.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0);
+  const int rc = dli::launch_all_reduce(reinterpret_cast<void*>(st), inp.data_ptr(), out.data_ptr(), inp.numel() * 2, (int)algo,
+                                        cur_stream(inp));
+  TORCH_CHECK(rc == 0, "custom all-reduce: message of ", inp.numel() * 2, " bytes not supported");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dli, m) {
+  m.def("ar_alloc(int bytes, bool uncached) -> int", &ar_alloc);
+  m.def("ar_free(int ptr) -> ()", &ar_free);
+  m.def("ar_ipc_handle(int ptr) -> Tensor", &ar_ipc_handle);
+  m.def("ar_ipc_open(Tensor handle) -> int", &ar_ipc_open);
+  m.def("ar_signal_bytes() -> int", &ar_signal_bytes);
+  m.def("ar_create(int rank, int world, Tensor staging, Tensor result, Tensor signal, int max_bytes) -> int", &ar_create);
+  m.def("ar_destroy(int state) -> ()", &ar_destroy);
+  m.def("ar_error(int state) -> int", &ar_error);
+  m.def("ar_all_reduce(int state, Tensor inp, Tensor(a!) out, int algo) -> ()", &ar_all_reduce);
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);

@@ -1,0 +1,54 @@
+"""Helper for test_custom_ar_gpu.py: one rank of a custom all-reduce group.  All ranks may share one
+physical GPU (the IPC mapping path is the same as across GPUs); bootstrap is gloo over TCP."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch
+import torch.distributed as dist
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    from dli_amd.parallel.custom_all_reduce import CustomAllReduce
+    from dli_amd.parallel.state import ParallelContext
+    ctx = ParallelContext(tp_size=world, tp_rank=rank, group=dist.group.WORLD, cpu_group=dist.group.WORLD)
+    ar = CustomAllReduce(ctx, dev, max_bytes=4 << 20)
+    results = {}
+    g = torch.Generator().manual_seed(100 + rank)
+    for numel, algo in ((8, 1), (4096, 1), (4096 * 33 + 8, 2), (1 << 20, 2), (1 << 20, 1), (2 << 20, 0)):
+        x_cpu = torch.randn(numel, generator=g).to(torch.bfloat16)
+        parts = [None] * world
+        dist.all_gather_object(parts, x_cpu)
+        want = torch.stack([p.float() for p in parts]).sum(0)
+        x = x_cpu.to(dev)
+        outs = [ar.all_reduce(x, algo) for _ in range(3)]          # back-to-back calls: epoch/flag reuse
+        torch.cuda.synchronize()
+        err = max(float((o.float().cpu() - want).abs().max()) for o in outs)
+        results[f"{numel}/{algo}"] = err
+    # graph replay: the epoch counter must advance on its own
+    x = torch.ones(4096, device=dev, dtype=torch.bfloat16) * (rank + 1)
+    out = torch.empty_like(x)
+    ar.lib.ar_all_reduce(ar.state, x, out, 1)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ar.lib.ar_all_reduce(ar.state, x, out, 1)
+    for _ in range(4):
+        gr.replay()
+    torch.cuda.synchronize()
+    results["graph"] = float((out.float() - world * (world + 1) / 2).abs().max())
+    results["error_flag"] = ar.error()
+    dist.barrier()
+    print("RESULT " + json.dumps(results), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
