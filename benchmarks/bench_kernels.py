@@ -147,6 +147,18 @@ def bench_sampler(quick):
                timeit(lambda: ops.sample(logits, one * 0.7, one * 0.9, zk + 50, seeds, steps, out=out)), B=B, V=V)
 
 
+def bench_moe(quick):
+    H, I, E = 4096, 14336, 8
+    for T, El in ([(256, 8)] if quick else [(256, 8), (256, 1), (4096, 8), (4096, 1)]):
+        x = torch.randn(T, H, device=DEV).bfloat16()
+        logits = torch.randn(T, E, device=DEV).bfloat16()
+        w13 = (torch.randn(El, 2 * I, H, device=DEV) * 0.02).bfloat16()
+        w2 = (torch.randn(El, H, I, device=DEV) * 0.02).bfloat16()
+        t = timeit(lambda: ops.fused_moe(x, logits, w13, w2, 2, 0), iters=10)
+        rows = T * 2 * El / E                                   # expected rows hitting local experts
+        report("fused_moe", t, flops=2 * rows * 3 * I * H, bytes_=El * 3 * I * H * 2, T=T, local_experts=El)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -169,6 +181,8 @@ def main():
         bench_prefill(a.quick)
     if run("sampler"):
         bench_sampler(a.quick)
+    if run("moe"):
+        bench_moe(a.quick)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,16 @@ void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int
                    const float* top_p, const int* top_k, const int64_t* seeds, const int64_t* steps, const float* noise,
                    int64_t* out, hipStream_t stream);
 
+// mixture of experts (moe.hip)
+void launch_moe_route(const void* logits, int T, int E, int K, int* ids, float* weights, hipStream_t stream);
+void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int* sorted_ids, int* tile_expert, int* meta,
+                      int capacity_rows, hipStream_t stream);
+void launch_grouped_gemm(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
+                         const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
+                         void* out, int64_t out_stride, int K, int N_out, int max_tiles, hipStream_t stream);
+void launch_moe_sum(const void* y, const int* ids, int expert_offset, int E_local, int top_k, int T, int H, void* out,
+                    hipStream_t stream);
+
 // custom all-reduce over IPC-mapped peer buffers (custom_all_reduce.hip)
 void* ar_alloc(size_t bytes, bool uncached);
 void ar_free(void* p);

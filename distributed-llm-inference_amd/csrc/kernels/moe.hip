@@ -1,0 +1,276 @@
+// K8: Mixtral-style mixture-of-experts on gfx950: routing, token alignment, grouped GEMM
+// on v_mfma_f32_16x16x32_bf16 with fused epilogues, and the weighted un-permute.
+//
+//   moe_route      softmax over all experts → top-k → renormalise               [T,E] → ids/weights [T,k]
+//   moe_align      bucket the (token, slot) pairs of the *local* experts; every expert's segment is
+//                  padded to a multiple of the GEMM row tile; all sizes stay on the device, so the
+//                  whole block is hipGraph-capturable (grids are launched at their worst-case size and
+//                  surplus tiles exit on a device-side count)
+//   grouped_gemm   C[rows of expert e] = A[rows] · W[e]ᵀ, 128×128×64 tiles, 4 waves (2×2) of 64×64,
+//                  A rows gathered by index straight into the (XOR-swizzled) LDS image, register
+//                  prefetch of the next K tile under the MFMAs.
+//                  EPI_SWIGLU: the 128 B-rows of a tile are 2×(32 gate + 32 up) weight rows, so each
+//                  wave owns matching gate/up columns and applies silu(g)·u in registers — the [rows, 2I]
+//                  intermediate never exists.
+//                  EPI_SCATTER: rows are scaled by their routing weight and stored at (token·k + slot).
+//   moe_sum        out[t] = Σ_slots y[t·k + slot] over the slots served by local experts (no atomics:
+//                  bitwise reproducible; non-local slots are summed in by the caller's all-reduce).
+#include "common.h"
+#include "kernels.h"
+
+namespace dli {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int MOE_MAX_E = 64;
+
+// ------------------------------------------------------------------------------------------ routing
+__global__ void moe_route_kernel(const uint16_t* __restrict__ logits, int T, int E, int K, int* __restrict__ ids,
+                                 float* __restrict__ weights) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  float v[MOE_MAX_E];
+  float mx = -3.0e38f;
+  for (int e = 0; e < E; ++e) {
+    v[e] = bf2f(logits[(int64_t)t * E + e]);
+    mx = fmaxf(mx, v[e]);
+  }
+  float sum = 0.f;
+  for (int e = 0; e < E; ++e) {
+    v[e] = __expf(v[e] - mx);
+    sum += v[e];
+  }
+  float picked = 0.f;
+  for (int k = 0; k < K; ++k) {
+    int best = 0;
+    float bv = -1.f;
+    for (int e = 0; e < E; ++e)
+      if (v[e] > bv) { bv = v[e]; best = e; }
+    ids[t * K + k] = best;
+    weights[t * K + k] = bv;
+    picked += bv;
+    v[best] = -2.f;
+  }
+  const float inv = 1.f / picked;      // renormalise over the chosen experts (softmax denominator cancels)
+  for (int k = 0; k < K; ++k) weights[t * K + k] *= inv;
+  (void)sum;
+}
+
+// ------------------------------------------------------------------------------------------ alignment
+// meta[0] = number of row tiles, meta[1] = padded row count
+__global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__ ids, int n, int expert_offset, int E_local,
+                                                         int* __restrict__ sorted_ids, int* __restrict__ tile_expert,
+                                                         int* __restrict__ meta, int capacity_rows) {
+  __shared__ int cnt[MOE_MAX_E], off[MOE_MAX_E + 1], pos[MOE_MAX_E];
+  for (int e = threadIdx.x; e < MOE_MAX_E; e += blockDim.x) { cnt[e] = 0; pos[e] = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int e = ids[i] - expert_offset;
+    if (e >= 0 && e < E_local) atomicAdd(&cnt[e], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    off[0] = 0;
+    for (int e = 0; e < E_local; ++e) {
+      const int padded = (cnt[e] + BM - 1) / BM * BM;
+      for (int t = off[e] / BM; t < (off[e] + padded) / BM; ++t) tile_expert[t] = e;
+      off[e + 1] = off[e] + padded;
+    }
+    meta[0] = off[E_local] / BM;
+    meta[1] = off[E_local];
+  }
+  __syncthreads();
+  const int total = off[E_local];
+  for (int i = threadIdx.x; i < capacity_rows; i += blockDim.x) sorted_ids[i] = -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int e = ids[i] - expert_offset;
+    if (e >= 0 && e < E_local) sorted_ids[off[e] + atomicAdd(&pos[e], 1)] = i;
+  }
+  (void)total;
+}
+
+// ------------------------------------------------------------------------------------------ grouped GEMM
+enum { EPI_SWIGLU = 0, EPI_SCATTER = 1 };
+
+// byte offset of 16-byte chunk c (0..7) of row r inside a [128][64] bf16 LDS tile, XOR-swizzled so that
+// the 16 rows a ds_read_b128 lane group touches fall on different bank groups
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void grouped_gemm_kernel(
+    const uint16_t* __restrict__ A, int64_t a_stride,         // EPI_SWIGLU: x [T, K], rows gathered; EPI_SCATTER: act [P, K]
+    const uint16_t* __restrict__ W, int64_t w_expert_stride,  // [E_local, N_total, K]
+    const int* __restrict__ sorted_ids, const int* __restrict__ tile_expert, const int* __restrict__ meta,
+    const float* __restrict__ topk_w, int top_k, uint16_t* __restrict__ out, int64_t out_stride, int K, int N_half) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * BM * BK * 2];
+  char* ldsA = lds;
+  char* ldsB = lds + BM * BK * 2;
+  const int tile = blockIdx.x;
+  if (tile >= meta[0]) return;
+  const int e = tile_expert[tile];
+  const uint16_t* We = W + (int64_t)e * w_expert_stride;
+  const int n0 = blockIdx.y * (EPI == EPI_SWIGLU ? BN / 2 : BN);   // SWIGLU: 64 output columns per tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int col = lane & 15, g = lane >> 4;
+
+  // ---- staging assignment: thread owns chunks q = tid + 256 i (i < 4): row q/8, chunk q%8, for A and B
+  const uint16_t* a_src[4];
+  const uint16_t* b_src[4];
+  int st_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + 256 * i, r = q >> 3, c = q & 7;
+    st_off[i] = lds_off(r, c);
+    int64_t arow;
+    if (EPI == EPI_SWIGLU) {
+      const int sid = sorted_ids[tile * BM + r];
+      arow = sid >= 0 ? sid / top_k : 0;                     // padding rows read token 0 (discarded later)
+    } else {
+      arow = (int64_t)tile * BM + r;
+    }
+    a_src[i] = A + arow * a_stride + c * 8;
+    int wrow;
+    if (EPI == EPI_SWIGLU) {
+      const int w_ = r >> 6, within = r & 63;                 // wave-column half, position inside it
+      wrow = (within < 32 ? 0 : N_half) + n0 + w_ * 32 + (within & 31);
+    } else {
+      wrow = n0 + r;
+    }
+    b_src[i] = We + (int64_t)wrow * K + c * 8;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  bf16x8 pa[4], pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pa[i] = *reinterpret_cast<const bf16x8*>(a_src[i]);
+    pb[i] = *reinterpret_cast<const bf16x8*>(b_src[i]);
+  }
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();                                           // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<bf16x8*>(ldsA + st_off[i]) = pa[i];
+      *reinterpret_cast<bf16x8*>(ldsB + st_off[i]) = pb[i];
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {                                         // prefetch the next K tile under the MFMAs
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pa[i] = *reinterpret_cast<const bf16x8*>(a_src[i] + (kt + 1) * BK);
+        pb[i] = *reinterpret_cast<const bf16x8*>(b_src[i] + (kt + 1) * BK);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(ldsA + lds_off(wm * 64 + m * 16 + col, ks * 4 + g));
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const bf16x8*>(ldsB + lds_off(wn * 64 + n * 16 + col, ks * 4 + g));
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = mfma16(fb[n], fa[m], acc[m][n]);
+      // operands swapped on purpose: D[row = weight column n (4g+r)][col = token row m (lane&15)], i.e. each
+      // lane holds 4 *consecutive output columns* of one token row → 8-byte row-contiguous stores
+    }
+  }
+
+  // ---- epilogue.  acc[m][n][r]: token row = wm*64 + m*16 + col, output column = wn*64 + n*16 + 4g + r
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int prow = tile * BM + wm * 64 + m * 16 + col;
+    const int sid = sorted_ids[prow];
+    if (EPI == EPI_SWIGLU) {
+      // wave columns: n = 0,1 gate (32 cols), n = 2,3 the matching up columns
+      uint16_t* dst = out + (int64_t)prow * out_stride + n0 + wn * 32 + 4 * g;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gate = acc[m][n][r], up = acc[m][n + 2][r];
+          o[r] = (short)f2bf(gate * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * gate)) * up);
+        }
+        *reinterpret_cast<bf16x4*>(dst + n * 16) = o;           // padding rows hold finite junk, never read back
+      }
+    } else if (sid >= 0) {
+      const float w = topk_w[sid];
+      uint16_t* dst = out + (int64_t)sid * out_stride + n0 + wn * 64 + 4 * g;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(acc[m][n][r] * w);
+        *reinterpret_cast<bf16x4*>(dst + n * 16) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ un-permute
+__global__ __launch_bounds__(256) void moe_sum_kernel(const uint16_t* __restrict__ y, const int* __restrict__ ids,
+                                                      int expert_offset, int E_local, int top_k, int H,
+                                                      uint16_t* __restrict__ out) {
+  const int t = blockIdx.x;
+  for (int v = threadIdx.x; v < H / 8; v += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < top_k; ++s) {
+      const int e = ids[t * top_k + s] - expert_offset;
+      if (e < 0 || e >= E_local) continue;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(y + ((int64_t)t * top_k + s) * H + v * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf2f((uint16_t)a[j]);
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(acc[j]);
+    *reinterpret_cast<bf16x8*>(out + (int64_t)t * H + v * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+void launch_moe_route(const void* logits, int T, int E, int K, int* ids, float* weights, hipStream_t stream) {
+  if (T == 0) return;
+  hipLaunchKernelGGL(moe_route_kernel, dim3((T + 127) / 128), dim3(128), 0, stream, (const uint16_t*)logits, T, E, K, ids, weights);
+}
+
+void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int* sorted_ids, int* tile_expert, int* meta,
+                      int capacity_rows, hipStream_t stream) {
+  hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), 0, stream, ids, n, expert_offset, E_local, sorted_ids, tile_expert,
+                     meta, capacity_rows);
+}
+
+void launch_grouped_gemm(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
+                         const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
+                         void* out, int64_t out_stride, int K, int N_out, int max_tiles, hipStream_t stream) {
+  if (max_tiles == 0) return;
+  if (epilogue == EPI_SWIGLU) {
+    dim3 grid(max_tiles, N_out / (BN / 2));
+    hipLaunchKernelGGL(grouped_gemm_kernel<EPI_SWIGLU>, grid, dim3(256), 0, stream, (const uint16_t*)A, a_stride,
+                       (const uint16_t*)W, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, (uint16_t*)out,
+                       out_stride, K, N_out);
+  } else {
+    dim3 grid(max_tiles, N_out / BN);
+    hipLaunchKernelGGL(grouped_gemm_kernel<EPI_SCATTER>, grid, dim3(256), 0, stream, (const uint16_t*)A, a_stride,
+                       (const uint16_t*)W, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, (uint16_t*)out,
+                       out_stride, K, N_out);
+  }
+}
+
+void launch_moe_sum(const void* y, const int* ids, int expert_offset, int E_local, int top_k, int T, int H, void* out,
+                    hipStream_t stream) {
+  if (T == 0) return;
+  hipLaunchKernelGGL(moe_sum_kernel, dim3(T), dim3(256), 0, stream, (const uint16_t*)y, ids, expert_offset, E_local, top_k, H,
+                     (uint16_t*)out);
+}
+
+}  // namespace dli

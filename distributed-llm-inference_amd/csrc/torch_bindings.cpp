@@ -160,6 +160,39 @@ void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const T
                      steps.data_ptr<int64_t>(), nz, out.data_ptr<int64_t>(), cur_stream(logits));
 }
 
+// ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
+Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
+                 int64_t expert_offset) {
+  check_bf16_rows(x, "x");
+  check_bf16_rows(router_logits, "router_logits");
+  TORCH_CHECK(x.is_contiguous() && router_logits.is_contiguous());
+  TORCH_CHECK(w13.is_cuda() && w2.is_cuda() && w13.is_contiguous() && w2.is_contiguous() && w13.scalar_type() == at::kBFloat16 &&
+              w2.scalar_type() == at::kBFloat16 && w13.dim() == 3 && w2.dim() == 3);
+  const int64_t T = x.size(0), H = x.size(1), E = router_logits.size(1), El = w13.size(0), I = w13.size(1) / 2;
+  TORCH_CHECK(router_logits.size(0) == T && w13.size(2) == H && w2.size(0) == El && w2.size(1) == H && w2.size(2) == I);
+  TORCH_CHECK(E <= 64 && top_k >= 1 && top_k <= E && H % 128 == 0 && I % 64 == 0, "unsupported MoE shape");
+  auto stream = cur_stream(x);
+  auto i32 = x.options().dtype(at::kInt);
+  const int64_t n = T * top_k;
+  const int64_t capacity = (n + 127) / 128 * 128 + El * 128;
+  const int64_t max_tiles = capacity / 128;
+  Tensor ids = at::empty({n}, i32), wts = at::empty({n}, x.options().dtype(at::kFloat));
+  Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
+  Tensor act = at::empty({capacity, I}, x.options()), y = at::empty({n, H}, x.options()), out = at::empty({T, H}, x.options());
+  dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
+  dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
+                        tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, stream);
+  dli::launch_grouped_gemm(0, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
+                           meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, act.data_ptr(), I, (int)H, (int)I,
+                           (int)max_tiles, stream);
+  dli::launch_grouped_gemm(1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
+                           meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H, (int)I, (int)H,
+                           (int)max_tiles, stream);
+  dli::launch_moe_sum(y.data_ptr(), ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k, (int)T, (int)H, out.data_ptr(),
+                      stream);
+  return out;
+}
+
 // ---- custom all-reduce: raw allocations + IPC handles travel as int64 / uint8 tensors -------------
 int64_t ar_alloc(int64_t bytes, bool uncached) {
   void* p = dli::ar_alloc((size_t)bytes, uncached);
@@ -202,6 +235,7 @@ void ar_all_reduce(int64_t st, const Tensor& inp, Tensor out, int64_t algo) {
 }  // namespace
 
 TORCH_LIBRARY(dli, m) {
+  m.def("fused_moe(Tensor x, Tensor router_logits, Tensor w13, Tensor w2, int top_k, int expert_offset) -> Tensor", &fused_moe);
   m.def("ar_alloc(int bytes, bool uncached) -> int", &ar_alloc);
   m.def("ar_free(int ptr) -> ()", &ar_free);
   m.def("ar_ipc_handle(int ptr) -> Tensor", &ar_ipc_handle);

@@ -103,3 +103,31 @@ def test_seeded_sampling_reproducible_across_batch_composition():
     while eng2.has_unfinished():
         eng2.step()
     assert np.mean(np.array(alone) == ra.output_ids) > 0.8           # same Philox stream whatever the batch
+
+
+def test_mixtral_engine_on_gpu_uses_hip_moe():
+    cfg = EngineConfig(model=get_model_config("tiny-mixtral-d128"), cache=CacheConfig(num_blocks=256),
+                       sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=256, max_model_len=1024),
+                       device="cuda", graph_batch_sizes=(4, 8))
+    eng = LLMEngine(cfg)
+    p = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True)
+    outs = eng.generate(None, p, prompt_ids=_prompts(9, (20, 150, 64)))
+    assert all(len(o) == 10 for o in outs) and eng.runner.stats["graph_steps"] > 0
+    # logits of the HIP path track the fp32 reference model
+    toks = _prompts(10, (90,))[0]
+    want = _ref_logits(eng, toks)
+    L = len(toks)
+    nb = (L + 31) // 32
+    r = eng.runner
+    caches = ops.allocate_kv_cache(cfg.model.num_layers, nb, 1, 128, torch.bfloat16, "cuda")
+    ts, t0 = ops.build_prefill_tiles(np.array([L]), 0, r.tile_tokens)
+    meta = ops.AttnMetadata(0, 1, L, torch.arange(L, dtype=torch.int32, device="cuda"),
+                            torch.arange(L, dtype=torch.int32, device="cuda"),
+                            torch.arange(nb, dtype=torch.int32, device="cuda")[None].contiguous(),
+                            torch.tensor([L], dtype=torch.int32, device="cuda"),
+                            torch.tensor([0, L], dtype=torch.int32, device="cuda"),
+                            prefill_tile_seq=torch.from_numpy(ts).cuda(), prefill_tile_q0=torch.from_numpy(t0).cuda(),
+                            num_prefill_tiles=len(ts))
+    with torch.inference_mode():
+        got = r.model.compute_logits(r.model(torch.tensor(toks, device="cuda"), meta, caches)).float().cpu()
+    assert torch.nn.functional.cosine_similarity(got, want, dim=-1).min() > 0.99

@@ -232,3 +232,23 @@ def test_copy_pages():
     want[6] = want[2]
     ops.copy_pages(kc, torch.tensor([[1, 5], [2, 6]], dtype=torch.int32, device=DEV))
     assert torch.equal(kc, want)
+
+
+@pytest.mark.parametrize("T,H,I,E,El,off", [(1, 512, 1024, 4, 4, 0), (300, 4096, 1792, 8, 8, 0), (77, 1024, 448, 8, 2, 4),
+                                             (1000, 512, 256, 8, 1, 3)])
+def test_fused_moe_matches_reference(T, H, I, E, El, off):
+    x = _bf(T, H, seed=41)
+    logits = _bf(T, E, seed=42, scale=2.0)
+    w13 = _bf(El, 2 * I, H, seed=43, scale=0.03)
+    w2 = _bf(El, H, I, seed=44, scale=0.03)
+    got = ops.fused_moe(x, logits, w13, w2, 2, off).float()
+    want = ref.moe_ref(x.float(), logits.float(), w13.float(), w2.float(), 2, off).float()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max() / want.abs().max().clamp_min(1e-6)
+    assert err < 3e-2, err
+    # tokens routed only to non-local experts contribute exactly zero
+    if El < E:
+        probs = torch.softmax(logits.float(), -1)
+        top = probs.topk(2, -1).indices
+        none_local = ((top < off) | (top >= off + El)).all(-1)
+        assert got[none_local].abs().max() == 0 if none_local.any() else True
