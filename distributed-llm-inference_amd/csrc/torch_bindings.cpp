@@ -164,7 +164,8 @@ void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const T
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
                  int64_t expert_offset) {
   check_bf16_rows(x, "x");
-  check_bf16_rows(router_logits, "router_logits");
+  TORCH_CHECK(router_logits.is_cuda() && router_logits.scalar_type() == at::kBFloat16 && router_logits.dim() == 2,
+              "router_logits must be a 2-D bfloat16 GPU tensor");
   TORCH_CHECK(x.is_contiguous() && router_logits.is_contiguous());
   TORCH_CHECK(w13.is_cuda() && w2.is_cuda() && w13.is_contiguous() && w2.is_contiguous() && w13.scalar_type() == at::kBFloat16 &&
               w2.scalar_type() == at::kBFloat16 && w13.dim() == 3 && w2.dim() == 3);
