@@ -50,7 +50,7 @@ def build_runtime(verbose: bool = False) -> str:
     import pybind11
 
     src = os.path.join(CSRC, "runtime", "block_manager.cpp")
-    if _newer([src], RUNTIME_SO):
+    if _newer([src, os.path.join(CSRC, "runtime", "block_manager.h")], RUNTIME_SO):
         cxx = os.environ.get("CXX", "g++")
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
                "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", RUNTIME_SO]

@@ -15,275 +15,32 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
-#include <cstdint>
-#include <stdexcept>
-#include <string>
-#include <unordered_map>
-#include <utility>
-#include <vector>
+#include "block_manager.h"
 
 namespace py = pybind11;
 
 namespace {
 
-inline uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
+using dli_rt::BlockManager;
+using i32arr = py::array_t<int32_t, py::array::c_style | py::array::forcecast>;
+using i64arr = py::array_t<int64_t, py::array::c_style | py::array::forcecast>;
+using i32out = py::array_t<int32_t, py::array::c_style>;
+
+int match_prefix(BlockManager& bm, int64_t id, i32arr tokens) { return bm.match_prefix(id, tokens.data(), static_cast<int>(tokens.size())); }
+void commit(BlockManager& bm, int64_t id, i32arr tokens, int num_computed) {
+  bm.commit(id, tokens.data(), static_cast<int>(tokens.size()), num_computed);
 }
-
-inline uint64_t hash_block(uint64_t parent, const int32_t* tok, int n) {
-  uint64_t h = mix64(parent ^ 0xA0761D6478BD642Full);
-  for (int i = 0; i < n; ++i) h = mix64(h ^ (static_cast<uint64_t>(static_cast<uint32_t>(tok[i])) + (uint64_t(i) << 32)));
-  return h ? h : 1;  // 0 is reserved for "no hash"
+int build_batch(BlockManager& bm, i64arr seq_ids, i32arr num_computed, i32arr num_new, i32out positions, i32out slot_mapping,
+                i32out block_tables, i32out seq_lens, i32out query_start_loc) {
+  const int B = static_cast<int>(seq_ids.size());
+  if (num_computed.size() != B || num_new.size() != B) throw std::invalid_argument("build_batch: length mismatch");
+  if (block_tables.ndim() != 2 || block_tables.shape(0) < B) throw std::invalid_argument("build_batch: block_tables too small");
+  if (seq_lens.size() < B || query_start_loc.size() < B + 1) throw std::invalid_argument("build_batch: seq_lens/query_start_loc too small");
+  return bm.build_batch(B, seq_ids.data(), num_computed.data(), num_new.data(), positions.mutable_data(),
+                        slot_mapping.mutable_data(), std::min<int64_t>(positions.size(), slot_mapping.size()),
+                        block_tables.mutable_data(), static_cast<int>(block_tables.shape(1)), seq_lens.mutable_data(),
+                        query_start_loc.mutable_data());
 }
-
-struct Block {
-  int ref = 0;
-  uint64_t hash = 0;  // 0 → not in the prefix cache
-  int lru_prev = -1, lru_next = -1;
-  bool in_lru = false;
-};
-
-struct Seq {
-  std::vector<int> blocks;
-  int hashed_blocks = 0;    // leading blocks whose chain hash has been computed
-  uint64_t chain = 0;       // hash of block hashed_blocks-1 (0 at the root)
-};
-
-class BlockManager {
- public:
-  BlockManager(int num_blocks, int block_size, bool prefix_caching)
-      : bs_(block_size), caching_(prefix_caching), blocks_(num_blocks) {
-    if (num_blocks <= 0 || block_size <= 0) throw std::invalid_argument("num_blocks and block_size must be > 0");
-    free_.reserve(num_blocks);
-    for (int i = num_blocks - 1; i >= 0; --i) free_.push_back(i);  // pop_back hands out 0,1,2,…
-  }
-
-  int num_blocks() const { return static_cast<int>(blocks_.size()); }
-  int block_size() const { return bs_; }
-  int num_free() const { return static_cast<int>(free_.size()) + lru_size_; }
-  int num_cached() const { return static_cast<int>(cache_.size()); }
-  bool has_seq(int64_t id) const { return seqs_.count(id) != 0; }
-  int64_t cache_hits() const { return hits_; }
-  int64_t cache_queries() const { return queries_; }
-
-  // Attach the longest cached prefix of `tokens` (whole blocks, and never the entire prompt: the last
-  // token must be recomputed to produce logits).  Returns the number of tokens covered.
-  int match_prefix(int64_t id, py::array_t<int32_t, py::array::c_style | py::array::forcecast> tokens) {
-    Seq& s = seqs_[id];
-    if (!s.blocks.empty()) throw std::runtime_error("match_prefix on a sequence that already owns blocks");
-    if (!caching_) return 0;
-    const int32_t* tok = tokens.data();
-    const int n = static_cast<int>(tokens.size());
-    const int max_blocks = (n - 1) / bs_;
-    uint64_t chain = 0;
-    for (int b = 0; b < max_blocks; ++b) {
-      uint64_t h = hash_block(chain, tok + size_t(b) * bs_, bs_);
-      ++queries_;
-      auto it = cache_.find(h);
-      if (it == cache_.end()) break;
-      ++hits_;
-      take(it->second);
-      s.blocks.push_back(it->second);
-      chain = h;
-    }
-    s.hashed_blocks = static_cast<int>(s.blocks.size());
-    s.chain = chain;
-    return s.hashed_blocks * bs_;
-  }
-
-  // Grow the block table so that `total_tokens` fit.  All-or-nothing.
-  bool allocate(int64_t id, int total_tokens) {
-    Seq& s = seqs_[id];
-    const int need = (total_tokens + bs_ - 1) / bs_ - static_cast<int>(s.blocks.size());
-    if (need <= 0) return true;
-    if (need > num_free()) return false;
-    for (int i = 0; i < need; ++i) s.blocks.push_back(pop_free());
-    return true;
-  }
-
-  bool can_allocate(int64_t id, int total_tokens) const {
-    auto it = seqs_.find(id);
-    const int have = it == seqs_.end() ? 0 : static_cast<int>(it->second.blocks.size());
-    return (total_tokens + bs_ - 1) / bs_ - have <= num_free();
-  }
-
-  // Publish the hashes of blocks that became full (tokens[0:num_computed] are in the cache).
-  void commit(int64_t id, py::array_t<int32_t, py::array::c_style | py::array::forcecast> tokens, int num_computed) {
-    if (!caching_) return;
-    Seq& s = at(id);
-    const int32_t* tok = tokens.data();
-    const int n = static_cast<int>(tokens.size());
-    if (num_computed > n) num_computed = n;
-    const int full = std::min(num_computed / bs_, static_cast<int>(s.blocks.size()));
-    for (int b = s.hashed_blocks; b < full; ++b) {
-      uint64_t h = hash_block(s.chain, tok + size_t(b) * bs_, bs_);
-      Block& blk = blocks_[s.blocks[b]];
-      if (blk.hash == 0 && cache_.find(h) == cache_.end()) {
-        blk.hash = h;
-        cache_.emplace(h, s.blocks[b]);
-      }
-      s.chain = h;
-      s.hashed_blocks = b + 1;
-    }
-  }
-
-  void free_seq(int64_t id) {
-    auto it = seqs_.find(id);
-    if (it == seqs_.end()) return;
-    auto& v = it->second.blocks;
-    for (auto r = v.rbegin(); r != v.rend(); ++r) release(*r);  // tail first → tail is evicted first
-    seqs_.erase(it);
-  }
-
-  // Child shares every block of the parent (n>1 sampling / beam style forks).
-  void fork(int64_t parent, int64_t child) {
-    const Seq& p = at(parent);
-    if (seqs_.count(child)) throw std::runtime_error("fork: child exists");
-    Seq c = p;
-    for (int b : c.blocks) ++blocks_[b].ref;
-    seqs_.emplace(child, std::move(c));
-  }
-
-  // Before appending into the last block: if it is shared, give this sequence a private copy.
-  // Returns (src, dst) for the device-side block copy, or (-1, -1) when nothing has to be copied.
-  std::pair<int, int> cow_tail(int64_t id, int num_tokens_in_seq) {
-    Seq& s = at(id);
-    if (s.blocks.empty() || num_tokens_in_seq % bs_ == 0) return {-1, -1};
-    const int idx = num_tokens_in_seq / bs_;
-    if (idx >= static_cast<int>(s.blocks.size())) return {-1, -1};
-    const int src = s.blocks[idx];
-    if (blocks_[src].ref <= 1) return {-1, -1};
-    if (num_free() < 1) throw std::runtime_error("cow_tail: out of blocks");
-    const int dst = pop_free();
-    --blocks_[src].ref;
-    s.blocks[idx] = dst;
-    if (s.hashed_blocks > idx) s.hashed_blocks = idx;
-    return {src, dst};
-  }
-
-  std::vector<int> block_table(int64_t id) const { return at(id).blocks; }
-  int ref_count(int block) const { return blocks_.at(block).ref; }
-
-  // Drop every unreferenced cached block (used by tests and on model reload).
-  void reset_prefix_cache() {
-    while (lru_head_ != -1) {
-      int b = lru_head_;
-      lru_remove(b);
-      cache_.erase(blocks_[b].hash);
-      blocks_[b].hash = 0;
-      free_.push_back(b);
-    }
-  }
-
-  // Fill one step's flattened metadata.  Sequence i contributes num_new[i] tokens at positions
-  // num_computed[i] … num_computed[i]+num_new[i]-1.  Returns the total token count.
-  int build_batch(py::array_t<int64_t, py::array::c_style | py::array::forcecast> seq_ids,
-                  py::array_t<int32_t, py::array::c_style | py::array::forcecast> num_computed,
-                  py::array_t<int32_t, py::array::c_style | py::array::forcecast> num_new,
-                  py::array_t<int32_t, py::array::c_style> positions, py::array_t<int32_t, py::array::c_style> slot_mapping,
-                  py::array_t<int32_t, py::array::c_style> block_tables, py::array_t<int32_t, py::array::c_style> seq_lens,
-                  py::array_t<int32_t, py::array::c_style> query_start_loc) {
-    const int B = static_cast<int>(seq_ids.size());
-    if (num_computed.size() != B || num_new.size() != B) throw std::invalid_argument("build_batch: length mismatch");
-    if (block_tables.ndim() != 2 || block_tables.shape(0) < B) throw std::invalid_argument("build_batch: block_tables too small");
-    if (seq_lens.size() < B || query_start_loc.size() < B + 1) throw std::invalid_argument("build_batch: seq_lens/query_start_loc too small");
-    const int max_blocks = static_cast<int>(block_tables.shape(1));
-    int32_t* pos = positions.mutable_data();
-    int32_t* slot = slot_mapping.mutable_data();
-    int32_t* bt = block_tables.mutable_data();
-    int32_t* sl = seq_lens.mutable_data();
-    int32_t* qs = query_start_loc.mutable_data();
-    const int64_t cap = std::min<int64_t>(positions.size(), slot_mapping.size());
-    int t = 0;
-    qs[0] = 0;
-    for (int i = 0; i < B; ++i) {
-      const Seq& s = at(seq_ids.data()[i]);
-      const int c = num_computed.data()[i], n = num_new.data()[i];
-      const int total = c + n;
-      const int nb = (total + bs_ - 1) / bs_;
-      if (nb > static_cast<int>(s.blocks.size())) throw std::runtime_error("build_batch: sequence lacks blocks for its new tokens");
-      if (nb > max_blocks) throw std::runtime_error("build_batch: block table row too short");
-      if (t + n > cap) throw std::runtime_error("build_batch: token buffers too small");
-      int32_t* row = bt + size_t(i) * max_blocks;
-      for (int b = 0; b < nb; ++b) row[b] = s.blocks[b];
-      for (int p = c; p < total; ++p, ++t) {
-        pos[t] = p;
-        slot[t] = s.blocks[p / bs_] * bs_ + p % bs_;
-      }
-      sl[i] = total;
-      qs[i + 1] = t;
-    }
-    return t;
-  }
-
- private:
-  Seq& at(int64_t id) {
-    auto it = seqs_.find(id);
-    if (it == seqs_.end()) throw std::out_of_range("unknown sequence id " + std::to_string(id));
-    return it->second;
-  }
-  const Seq& at(int64_t id) const {
-    auto it = seqs_.find(id);
-    if (it == seqs_.end()) throw std::out_of_range("unknown sequence id " + std::to_string(id));
-    return it->second;
-  }
-
-  void lru_push_back(int b) {
-    Block& k = blocks_[b];
-    k.lru_prev = lru_tail_;
-    k.lru_next = -1;
-    if (lru_tail_ != -1) blocks_[lru_tail_].lru_next = b; else lru_head_ = b;
-    lru_tail_ = b;
-    k.in_lru = true;
-    ++lru_size_;
-  }
-  void lru_remove(int b) {
-    Block& k = blocks_[b];
-    if (k.lru_prev != -1) blocks_[k.lru_prev].lru_next = k.lru_next; else lru_head_ = k.lru_next;
-    if (k.lru_next != -1) blocks_[k.lru_next].lru_prev = k.lru_prev; else lru_tail_ = k.lru_prev;
-    k.lru_prev = k.lru_next = -1;
-    k.in_lru = false;
-    --lru_size_;
-  }
-  void take(int b) {  // reference a cached block
-    Block& k = blocks_[b];
-    if (k.in_lru) lru_remove(b);
-    ++k.ref;
-  }
-  int pop_free() {
-    int b;
-    if (!free_.empty()) {
-      b = free_.back();
-      free_.pop_back();
-    } else {  // evict the least recently released cached block
-      b = lru_head_;
-      if (b == -1) throw std::runtime_error("pop_free: no block available");
-      lru_remove(b);
-      cache_.erase(blocks_[b].hash);
-      blocks_[b].hash = 0;
-    }
-    blocks_[b].ref = 1;
-    return b;
-  }
-  void release(int b) {
-    Block& k = blocks_[b];
-    if (k.ref <= 0) throw std::runtime_error("release: block is not referenced");
-    if (--k.ref > 0) return;
-    if (k.hash != 0) lru_push_back(b); else free_.push_back(b);
-  }
-
-  int bs_;
-  bool caching_;
-  std::vector<Block> blocks_;
-  std::vector<int> free_;
-  std::unordered_map<uint64_t, int> cache_;
-  std::unordered_map<int64_t, Seq> seqs_;
-  int lru_head_ = -1, lru_tail_ = -1, lru_size_ = 0;
-  int64_t hits_ = 0, queries_ = 0;
-};
 
 }  // namespace
 
@@ -298,15 +55,15 @@ PYBIND11_MODULE(_runtime, m) {
       .def_property_readonly("cache_hits", &BlockManager::cache_hits)
       .def_property_readonly("cache_queries", &BlockManager::cache_queries)
       .def("has_seq", &BlockManager::has_seq)
-      .def("match_prefix", &BlockManager::match_prefix)
+      .def("match_prefix", &match_prefix)
       .def("allocate", &BlockManager::allocate)
       .def("can_allocate", &BlockManager::can_allocate)
-      .def("commit", &BlockManager::commit)
+      .def("commit", &commit)
       .def("free_seq", &BlockManager::free_seq)
       .def("fork", &BlockManager::fork)
       .def("cow_tail", &BlockManager::cow_tail)
       .def("block_table", &BlockManager::block_table)
       .def("ref_count", &BlockManager::ref_count)
       .def("reset_prefix_cache", &BlockManager::reset_prefix_cache)
-      .def("build_batch", &BlockManager::build_batch);
+      .def("build_batch", &build_batch);
 }

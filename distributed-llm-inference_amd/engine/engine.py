@@ -18,6 +18,7 @@ from ..config import EngineConfig, KV_BLOCK_SIZE, SamplingParams
 from ..parallel.state import SINGLE, ParallelContext
 from ..runtime.block_manager import BlockManager
 from ..runtime.model_runner import ModelRunner
+from ..utils.profiling import trace_range
 from .metrics import EngineMetrics
 from .request import Request, RequestOutput, RequestStatus
 from .scheduler import Scheduler
@@ -92,16 +93,22 @@ class LLMEngine:
     # ------------------------------------------------------------------ one step
     def step(self) -> list[RequestOutput]:
         t0 = time.perf_counter()
-        batch = self.scheduler.schedule()
+        with trace_range("schedule"):
+            batch = self.scheduler.schedule()
         if batch is None:
             return []
         t1 = time.perf_counter()
         for r in batch.requests:
             if r.first_scheduled is None:
                 r.first_scheduled = t1
-        sampled = self.runner.execute(batch, self.bm)
+        if self.ctx.tp_size > 1 and self.metrics.steps % 128 == 0:
+            from ..runtime.tp_launcher import check_children
+            check_children()                                 # a dead TP worker would hang the next collective
+        with trace_range(f"execute[T={batch.total_tokens},B={len(batch.requests)}]"):
+            sampled = self.runner.execute(batch, self.bm)
         t2 = time.perf_counter()
-        results = self.scheduler.update(batch, sampled, self.cfg.model.eos_token_id, self.cfg.sched.max_model_len)
+        with trace_range("update"):
+            results = self.scheduler.update(batch, sampled, self.cfg.model.eos_token_id, self.cfg.sched.max_model_len)
         outs = []
         for req, tok, status in results:
             if tok is None:

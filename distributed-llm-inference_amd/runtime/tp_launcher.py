@@ -77,6 +77,13 @@ def maybe_launch_tp(cfg: EngineConfig, base_index: int = 0) -> Optional[Parallel
     return ctx
 
 
+def check_children():
+    """Failure detection for the TP group: raises if a worker process has exited."""
+    for p in _children:
+        if not p.is_alive():
+            raise RuntimeError(f"tensor-parallel worker {p.name} died (exit code {p.exitcode}); aborting the engine")
+
+
 def join_children(timeout: float = 20.0):
     for p in _children:
         p.join(timeout)
