@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--kv-dtype", default="auto")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--num-kv-blocks", type=int, default=None, help="fix the KV cache size (default: fill free HBM)")
     ap.add_argument("--dump", default="", help="write per-request records of rank 0 to this JSON file")
     return ap.parse_args()
 
@@ -73,19 +74,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
+    # one rank per GPU; DLI_BENCH_BACKEND=gloo lets several ranks share one GPU to rehearse the multi-rank path
+    backend = os.environ.get("DLI_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dli_amd.config import CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config
     from dli_amd.engine.engine import LLMEngine
     import synth
 
     mcfg = get_model_config(args.model)
-    cfg = EngineConfig(model=mcfg, cache=CacheConfig(kv_dtype=args.kv_dtype),
+    cfg = EngineConfig(model=mcfg, cache=CacheConfig(kv_dtype=args.kv_dtype, num_blocks=args.num_kv_blocks),
                        sched=SchedulerConfig(max_num_seqs=args.max_num_seqs,
                                              max_num_batched_tokens=args.max_batched_tokens,
                                              max_model_len=2112, long_prefill_chunk=args.chunk),
