@@ -70,6 +70,12 @@ MODEL_PRESETS: dict[str, ModelConfig] = {
     "tiny-llama-d128": ModelConfig(name="tiny-llama-d128", vocab_size=1024, hidden_size=512,
                                    intermediate_size=1024, num_layers=2, num_heads=4, num_kv_heads=1,
                                    head_dim=128, max_position=4096),
+    # TP-shardable D=128 shapes for the GPU TP tests (2 KV heads, 4 experts)
+    "tiny-llama-tp": ModelConfig(name="tiny-llama-tp", vocab_size=1024, hidden_size=512, intermediate_size=1024,
+                                 num_layers=2, num_heads=8, num_kv_heads=2, head_dim=128, max_position=4096),
+    "tiny-mixtral-tp": ModelConfig(name="tiny-mixtral-tp", arch="mixtral", vocab_size=1024, hidden_size=512,
+                                   intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=2, head_dim=128,
+                                   max_position=4096, num_experts=4, top_k_experts=2),
     "tiny-mixtral-d128": ModelConfig(name="tiny-mixtral-d128", arch="mixtral", vocab_size=1024, hidden_size=512,
                                      intermediate_size=1024, num_layers=2, num_heads=4, num_kv_heads=1,
                                      head_dim=128, max_position=4096, num_experts=4, top_k_experts=2),

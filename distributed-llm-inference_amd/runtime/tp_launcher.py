@@ -29,8 +29,10 @@ def _free_port() -> int:
 def _device_for(cfg: EngineConfig, rank: int, base_index: int) -> torch.device:
     use_gpu = cfg.device == "cuda" or (cfg.device == "auto" and torch.cuda.is_available())
     if use_gpu:
-        torch.cuda.set_device(base_index + rank)
-        return torch.device("cuda", base_index + rank)
+        # DLI_TP_SHARE_GPU=1: every rank on the same device (single-GPU rehearsal of the TP path, gloo backend)
+        idx = base_index if os.environ.get("DLI_TP_SHARE_GPU") == "1" else base_index + rank
+        torch.cuda.set_device(idx)
+        return torch.device("cuda", idx)
     return torch.device("cpu")
 
 

@@ -1,0 +1,35 @@
+"""Helper for test_tp_gpu.py: TP=k generation on GPU(s).  With DLI_TP_SHARE_GPU=1 all ranks share one
+device and talk over gloo (the custom all-reduce still uses HIP IPC between the processes)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from dli_amd.config import (CacheConfig, EngineConfig, ParallelConfig, SamplingParams, SchedulerConfig,
+                            get_model_config)
+from dli_amd.engine.engine import LLMEngine
+from dli_amd.runtime.tp_launcher import join_children, maybe_launch_tp
+
+
+def main():
+    model, tp, ep, backend = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    prompts = json.loads(sys.argv[5])
+    cfg = EngineConfig(model=get_model_config(model), cache=CacheConfig(num_blocks=512),
+                       sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=2048,
+                                             long_prefill_chunk=2048),
+                       parallel=ParallelConfig(tp=tp, ep=ep, backend=backend), device="cuda",
+                       graph_batch_sizes=(4, 8))
+    ctx = maybe_launch_tp(cfg)
+    eng = LLMEngine(cfg, ctx)
+    eng.warmup()
+    out = eng.generate(None, SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True), prompt_ids=prompts)
+    info = {"greedy": out, "graph_steps": eng.runner.stats["graph_steps"],
+            "custom_ar": bool(ctx is not None and ctx.custom_ar is not None)}
+    eng.shutdown()
+    join_children()
+    print("RESULT " + json.dumps(info))
+
+
+if __name__ == "__main__":
+    main()
