@@ -126,6 +126,27 @@ __global__ __launch_bounds__(512) void all_reduce_kernel(Peers p, int rank, int 
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
 }
 
+// All-gather with the same protocol: out[r][i] = in_r[i] (rank-major).  Used for the vocab-parallel logits so
+// that a TP decode graph contains no library collective at all.
+__global__ __launch_bounds__(512) void all_gather_kernel(Peers p, int rank, int world, const uint16_t* __restrict__ in,
+                                                         uint16_t* __restrict__ out, int64_t n_vec) {
+  Signal* self = p.signal[rank];
+  const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bf16x8* src = reinterpret_cast<const bf16x8*>(in);
+  bf16x8* mine = reinterpret_cast<bf16x8*>(p.staging[rank]);
+  for (int64_t i = tid; i < n_vec; i += stride) mine[i] = src[i];
+  mesh_barrier<0>(p, rank, world, flag);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out);
+  for (int r = 0; r < world; ++r) {
+    const bf16x8* peer = reinterpret_cast<const bf16x8*>(p.staging[r]);
+    for (int64_t i = tid; i < n_vec; i += stride) dst[r * n_vec + i] = peer[i];
+  }
+  mesh_barrier<2>(p, rank, world, flag);
+  if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+}
+
 // ---- host API (opaque handle; pointers are exchanged by the python layer through hipIpc handles) ----
 void* ar_alloc(size_t bytes, bool uncached) {
   void* p = nullptr;
@@ -184,6 +205,17 @@ int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int al
   else
     hipLaunchKernelGGL(all_reduce_kernel<false>, dim3(blocks), dim3(512), 0, stream, s->peers, s->rank, s->world,
                        (const uint16_t*)in, (uint16_t*)out, n_vec);
+  return 0;
+}
+
+int launch_all_gather(void* st, const void* in, void* out, int64_t bytes, hipStream_t stream) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  if (bytes % 16 != 0 || (size_t)bytes > s->max_bytes) return -1;
+  const int64_t n_vec = bytes / 16;
+  int blocks = (int)std::min<int64_t>((n_vec + 511) / 512, 36);
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(all_gather_kernel, dim3(blocks), dim3(512), 0, stream, s->peers, s->rank, s->world, (const uint16_t*)in,
+                     (uint16_t*)out, n_vec);
   return 0;
 }
 

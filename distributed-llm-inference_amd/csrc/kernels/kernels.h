@@ -50,5 +50,6 @@ void* ar_create(int rank, int world, const int64_t* staging, const int64_t* resu
 void ar_destroy(void* st);
 int ar_error(void* st);
 int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, hipStream_t stream);
+int launch_all_gather(void* st, const void* in, void* out, int64_t bytes, hipStream_t stream);
 
 }  // namespace dli

@@ -233,6 +233,14 @@ void ar_all_reduce(int64_t st, const Tensor& inp, Tensor out, int64_t algo) {
   TORCH_CHECK(rc == 0, "custom all-reduce: message of ", inp.numel() * 2, " bytes not supported");
 }
 
+void ar_all_gather(int64_t st, const Tensor& inp, Tensor out) {
+  TORCH_CHECK(inp.is_cuda() && out.is_cuda() && inp.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16);
+  TORCH_CHECK(inp.is_contiguous() && out.is_contiguous() && out.numel() % inp.numel() == 0);
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(inp.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0);
+  const int rc = dli::launch_all_gather(reinterpret_cast<void*>(st), inp.data_ptr(), out.data_ptr(), inp.numel() * 2, cur_stream(inp));
+  TORCH_CHECK(rc == 0, "custom all-gather: message of ", inp.numel() * 2, " bytes not supported");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(dli, m) {
@@ -246,6 +254,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("ar_destroy(int state) -> ()", &ar_destroy);
   m.def("ar_error(int state) -> int", &ar_error);
   m.def("ar_all_reduce(int state, Tensor inp, Tensor(a!) out, int algo) -> ()", &ar_all_reduce);
+  m.def("ar_all_gather(int state, Tensor inp, Tensor(a!) out) -> ()", &ar_all_gather);
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);

@@ -18,7 +18,7 @@ from .. import ops
 
 
 class CustomAllReduce:
-    def __init__(self, ctx, device, max_bytes: int = 8 << 20):
+    def __init__(self, ctx, device, max_bytes: int = 32 << 20):
         lib = ops.hip()
         self.lib, self.ctx, self.device, self.max_bytes = lib, ctx, device, max_bytes
         self.world, self.rank = ctx.tp_size, ctx.tp_rank
@@ -42,7 +42,7 @@ class CustomAllReduce:
         dist.barrier(group=group)
 
     @classmethod
-    def create(cls, ctx, device, max_bytes: int = 8 << 20):
+    def create(cls, ctx, device, max_bytes: int = 32 << 20):
         """Returns a verified instance, or ``None`` (→ RCCL only) if set-up or the self-test fails."""
         try:
             ar = cls(ctx, device, max_bytes)
@@ -61,22 +61,33 @@ class CustomAllReduce:
         self.lib.ar_all_reduce(self.state, x, out, algo)
         return out
 
+    def all_gather(self, x: torch.Tensor) -> torch.Tensor:
+        """``[world, *x.shape]`` (rank-major) — same IPC protocol, no library collective."""
+        out = torch.empty((self.world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        self.lib.ar_all_gather(self.state, x, out)
+        return out
+
     def error(self) -> bool:
         return bool(self.lib.ar_error(self.state))
 
     def self_test(self) -> bool:
+        """Compare against sums exchanged over the CPU group (works whatever the device backend is)."""
         ok = True
-        g = torch.Generator(device=self.device).manual_seed(1234 + self.rank)
+        group = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
+        g = torch.Generator().manual_seed(1234 + self.rank)
         for numel, algo in ((4096, 1), (1 << 20, 2), (3 * 4096 + 8, 2), (1 << 18, 0)):
-            x = torch.randn(numel, generator=g, device=self.device).to(torch.bfloat16)
-            want = x.float().clone()
-            dist.all_reduce(want, group=self.ctx.group)
-            got = self.all_reduce(x, algo).float()
-            torch.cuda.synchronize()
+            x_cpu = torch.randn(numel, generator=g).to(torch.bfloat16)
+            parts = [None] * self.world
+            dist.all_gather_object(parts, x_cpu, group=group)
+            want = torch.stack([p.float() for p in parts]).sum(0)
+            x = x_cpu.to(self.device)
+            got = self.all_reduce(x, algo).float().cpu()
+            gathered = self.all_gather(x).cpu()
             ok &= bool(torch.allclose(got, want, rtol=2e-2, atol=2e-2)) and not self.error()
-        flag = torch.tensor([int(ok)], device=self.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.ctx.group)
-        self.enabled = bool(flag.item())
+            ok &= all(torch.equal(gathered[r], parts[r]) for r in range(self.world))
+        votes = [None] * self.world
+        dist.all_gather_object(votes, ok, group=group)
+        self.enabled = all(votes)
         return self.enabled
 
     def close(self):

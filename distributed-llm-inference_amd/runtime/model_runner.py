@@ -56,6 +56,10 @@ class ModelRunner:
         self.kv_caches = allocate_kv_cache(mcfg.num_layers, self.num_blocks, self.local_kv_heads, mcfg.head_dim,
                                            self.kv_dtype, device)
         self._alloc_buffers()
+        if self.ctx.tp_size > 1 and self.on_gpu and cfg.use_hip_graphs:
+            import torch.distributed as dist
+            if dist.get_backend(self.ctx.group) != "nccl" and self.ctx.custom_ar is None:
+                cfg.use_hip_graphs = False                   # gloo collectives synchronise the host: not capturable
         self.graphs: dict[int, tuple] = {}
         self.graph_pool = None
         self.tile_tokens = ops.prefill_tile_tokens(self.local_heads, self.local_kv_heads)
