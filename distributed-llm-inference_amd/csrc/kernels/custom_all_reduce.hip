@@ -53,22 +53,31 @@ struct ARState {
 
 template <int PHASE>   // 0 start, 1 mid, 2 end
 __device__ __forceinline__ void mesh_barrier(const Peers& p, int rank, int world, uint32_t flag) {
-  __threadfence_system();          // every thread: my data stores are visible system-wide …
-  __syncthreads();                 // … before any thread of the block raises the flag
+  // publish/consume recipe of the CDNA guide (§6 G16): every storing wave drains its stores, the block
+  // meets, ONE wave releases (L2 write-back) and waits for it, then raises the flags; after the poll the
+  // same wave acquires (cache invalidate) and WAITS for the invalidate before the block is released —
+  // buffer_inv completes asynchronously, and without that wait the other waves can read stale lines of a
+  // peer's staging buffer (same addresses are reused by every call).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x < world) {
     Signal* peer = p.signal[threadIdx.x];
     Signal* self = p.signal[rank];
     uint32_t* dst = PHASE == 0 ? &peer->start[blockIdx.x][rank] : PHASE == 1 ? &peer->mid[blockIdx.x][rank] : &peer->end[blockIdx.x][rank];
     uint32_t* src = PHASE == 0 ? &self->start[blockIdx.x][threadIdx.x] : PHASE == 1 ? &self->mid[blockIdx.x][threadIdx.x] : &self->end[blockIdx.x][threadIdx.x];
-    __hip_atomic_store(dst, flag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 // system scope
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(dst, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned spins = 0;
-    while (__hip_atomic_load(src, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != flag) {
+    while (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != flag) {
       if (++spins > kSpinLimit) {
         __hip_atomic_store(&self->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
 }

@@ -96,7 +96,7 @@ class RowParallelLinear(nn.Module):
     inputs take the single-kernel custom all-reduce inside the hipGraph instead (latency-bound, nothing
     to overlap with)."""
 
-    OVERLAP_MIN_ROWS = 1024
+    OVERLAP_MIN_ROWS = int(__import__('os').environ.get('DLI_OVERLAP_MIN_ROWS', '1024'))
     OVERLAP_CHUNKS = 4
 
     def __init__(self, in_features: int, out_features: int, ctx: ParallelContext, dtype, device, bias: bool = False,
@@ -111,10 +111,19 @@ class RowParallelLinear(nn.Module):
         # the bias must be added once, not tp times: only rank 0 adds it before the reduction
         b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
         if (self.reduce and self.ctx.tp_size > 1 and x.is_cuda and x.dim() == 2 and x.shape[0] >= self.OVERLAP_MIN_ROWS
-                and not torch.cuda.is_current_stream_capturing()):
+                and self._stream_ordered_backend() and not torch.cuda.is_current_stream_capturing()):
             return self._forward_overlapped(x, b)
         y = F.linear(x, self.weight.data, b)
         return self.ctx.all_reduce(y) if self.reduce else y
+
+    def _stream_ordered_backend(self) -> bool:
+        """The pipeline relies on stream-ordered collectives (RCCL).  gloo moves CUDA tensors through host
+        buffers on its own threads/streams; in the single-GPU rehearsal mode (DLI_TP_SHARE_GPU=1) that path
+        produced rank-divergent sums under skew, so it stays on the plain GEMM → all-reduce sequence."""
+        if not hasattr(self, "_nccl"):
+            import torch.distributed as dist
+            self._nccl = dist.get_backend(self.ctx.group) == "nccl"
+        return self._nccl
 
     def _forward_overlapped(self, x, b):
         import torch.distributed as dist

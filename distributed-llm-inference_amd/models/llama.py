@@ -23,6 +23,28 @@ from .layers import (ColumnParallelLinear, ParallelLMHead, ReplicatedLinear, Row
                      VocabParallelEmbedding, Weight)
 
 
+_EP_DEBUG = __import__("os").environ.get("DLI_DEBUG_EP_CHECK") == "1"
+
+
+def _rank_check(ctx, tag, t):
+    """Debug aid (DLI_DEBUG_EP_CHECK=1): replicated activations must be bit-identical on every rank."""
+    import torch.distributed as dist
+    if not (_EP_DEBUG and ctx.tp_size > 1) or torch.cuda.is_current_stream_capturing():
+        return
+    rows = t.reshape(t.shape[0], -1).view(torch.int16).to(torch.int64).sum(-1).cpu()
+    got = [None] * ctx.tp_size
+    dist.all_gather_object(got, rows, group=ctx.cpu_group if ctx.cpu_group is not None else ctx.group)
+    if ctx.tp_rank == 0:
+        bad = (got[0] != got[1]).nonzero().flatten().tolist()
+        if bad:
+            print(f"[ep-check] {tag} T={t.shape[0]}: {len(bad)} rows differ, first {bad[:6]} last {bad[-3:]}", flush=True)
+
+
+def _ep_consistency_check(ctx, h, logits):
+    _rank_check(ctx, "moe-input", h)
+    _rank_check(ctx, "router-logits", logits)
+
+
 class Attention(nn.Module):
     def __init__(self, cfg: ModelConfig, ctx: ParallelContext, dtype, device, bias: bool = False, rope: bool = True):
         super().__init__()
@@ -83,6 +105,8 @@ class MoEBlock(nn.Module):
 
     def forward(self, h):
         logits = self.router(h)
+        if _EP_DEBUG and self.ctx.tp_size > 1 and not torch.cuda.is_current_stream_capturing():
+            _ep_consistency_check(self.ctx, h, logits)
         out = ops.fused_moe(h, logits, self.w13.data, self.w2.data, self.top_k, self.expert_offset)
         return self.ctx.all_reduce(out)
 
@@ -104,6 +128,7 @@ class DecoderLayer(nn.Module):
         else:
             ops.fused_add_rms_norm(h, residual, self.input_norm.data, self.eps)
         h = self.attn(h, meta, kv, cos_sin)
+        _rank_check(self.attn.o.ctx, "attn-out", h)
         ops.fused_add_rms_norm(h, residual, self.post_norm.data, self.eps)
         h = self.mlp(h)
         return h, residual
@@ -128,6 +153,7 @@ class LlamaForCausalLM(nn.Module):
 
     def forward(self, input_ids: torch.Tensor, meta, kv_caches) -> torch.Tensor:
         h = self.embed(input_ids)
+        _rank_check(self.ctx, "embed", h)
         residual = None
         for layer, kv in zip(self.layers, kv_caches):
             h, residual = layer(h, residual, meta, kv, self.cos_sin)

@@ -198,6 +198,6 @@ def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w
               expert_offset: int = 0) -> torch.Tensor:
     """Mixtral MoE block for the experts held by this rank (partial sum; caller all-reduces)."""
     from . import moe as _moe
-    if x.is_cuda and _moe.hip_moe_supported(x, w13):
+    if x.is_cuda and os.environ.get('DLI_MOE_REF') != '1' and _moe.hip_moe_supported(x, w13):
         return _moe.fused_moe_hip(x, router_logits, w13, w2, top_k, expert_offset)
     return ref.moe_ref(x, router_logits, w13, w2, top_k, expert_offset)

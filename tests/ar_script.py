@@ -32,6 +32,26 @@ def main():
         torch.cuda.synchronize()
         err = max(float((o.float().cpu() - want).abs().max()) for o in outs)
         results[f"{numel}/{algo}"] = err
+    # skew stress: one rank arrives late (extra GPU work + host sleep), fresh data every call, the result is
+    # checked against the exact sum; this is what catches stale reads of a peer's staging buffer
+    import time
+    bad = 0
+    big = torch.randn(2048, 2048, device=dev)
+    for it in range(120):
+        numel = (1247 * 512, 4096 * 24, 640 * 512)[it % 3]
+        base = torch.full((numel,), float(it % 7 + 1), device=dev, dtype=torch.bfloat16)
+        x = base * (rank + 1)
+        if it % world == rank:                       # the late rank of this round
+            for _ in range(3):
+                big = (big @ big).clamp_(-1, 1)
+            if it % 5 == 0:
+                time.sleep(0.003)
+        y = ar.all_reduce(x, 1 if it % 2 else 0)
+        want = float(it % 7 + 1) * world * (world + 1) / 2
+        bad += int((y.float() != want).sum().item() > 0)
+        g2 = ar.all_gather(x[:4096])
+        bad += int(any(float(g2[r][0]) != float(it % 7 + 1) * (r + 1) for r in range(world)))
+    results["skew_stress_bad"] = float(bad)
     # graph replay: the epoch counter must advance on its own
     x = torch.ones(4096, device=dev, dtype=torch.bfloat16) * (rank + 1)
     out = torch.empty_like(x)

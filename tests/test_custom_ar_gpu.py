@@ -34,5 +34,6 @@ def test_custom_all_reduce_ipc(world):
         assert p.returncode == 0, o[-3000:]
         res = json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:])
         assert res.pop("error_flag") is False
+        assert res.pop("skew_stress_bad") == 0, res
         for k, err in res.items():
             assert err <= 0.07 * world, (k, err, res)      # bf16 rounding of a sum of `world` unit normals

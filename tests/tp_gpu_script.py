@@ -18,7 +18,8 @@ def main():
     cfg = EngineConfig(model=get_model_config(model), cache=CacheConfig(num_blocks=512),
                        sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=2048,
                                              long_prefill_chunk=2048),
-                       parallel=ParallelConfig(tp=tp, ep=ep, backend=backend), device="cuda",
+                       parallel=ParallelConfig(tp=tp, ep=ep, backend=backend,
+                                               custom_all_reduce=os.environ.get("DLI_NO_CUSTOM_AR") != "1"), device="cuda",
                        graph_batch_sizes=(4, 8))
     ctx = maybe_launch_tp(cfg)
     eng = LLMEngine(cfg, ctx)
