@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--router-replicas", type=int, default=0, help="put the DP router in front of N replicas")
     ap.add_argument("--server-args", default="", help="extra args for api_server, space separated")
     a = ap.parse_args()
+    a.out_dir = os.path.abspath(a.out_dir)
     os.makedirs(a.out_dir, exist_ok=True)
     tg_dir = os.path.join(ROOT, "traffic_generator")
 
