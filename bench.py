@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=2048)
     ap.add_argument("--kv-dtype", default="auto")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="disable pipelined stepping (one step in flight at a time)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--num-kv-blocks", type=int, default=None, help="fix the KV cache size (default: fill free HBM)")
     ap.add_argument("--dump", default="", help="write per-request records of rank 0 to this JSON file")
@@ -96,7 +97,8 @@ def main():
                        sched=SchedulerConfig(max_num_seqs=args.max_num_seqs,
                                              max_num_batched_tokens=args.max_batched_tokens,
                                              max_model_len=2112, long_prefill_chunk=args.chunk),
-                       device="cuda", seed=args.seed, use_hip_graphs=not args.no_graphs)
+                       device="cuda", seed=args.seed, use_hip_graphs=not args.no_graphs,
+                       async_scheduling=not args.sync_steps)
     t_load = time.perf_counter()
     eng = LLMEngine(cfg, device=dev)
     eng.warmup()
@@ -153,8 +155,12 @@ def main():
     steps_before = (eng.metrics.steps, eng.metrics.step_tokens, eng.metrics.sched_time, eng.metrics.exec_time,
                     eng.metrics.post_time, dict(eng.runner.stats))
     t_start = time.perf_counter()
-    for _ in range(args.steps):
+    beat = t_start
+    for i in range(args.steps):
         one_step()
+        if rank == 0 and time.perf_counter() - beat > 30.0:         # keep long runs visibly alive
+            beat = time.perf_counter()
+            print(f"[bench] step {i + 1}/{args.steps}, {beat - t_start:.0f} s", file=sys.stderr, flush=True)
     sync()
     t_end = time.perf_counter()
     elapsed = t_end - t_start
@@ -191,7 +197,7 @@ def main():
         finished = sum(s["finished"] for s in allstats)
         value = good / T
         line = {
-            "metric": "slo_goodput_req_per_s (TTFT<=2s & TPOT<=100ms, BurstGPT replay, Llama-3-8B)",
+            "metric": f"slo_goodput_req_per_s (TTFT<=2s & TPOT<=100ms, BurstGPT replay, {args.model})",
             "value": round(value, 3), "unit": "req/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(T / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": round(value / BASELINE_GOODPUT, 1), "dtype": "bf16",
@@ -199,7 +205,8 @@ def main():
                     "random token ids, random-init weights)",
             "config": {"model": args.model, "global_batch": args.max_num_seqs * world, "seq_len": 2048,
                        "parallelism": f"dp{world}", "offered_qps": args.qps * world, "kv_dtype": args.kv_dtype,
-                       "max_num_batched_tokens": args.max_batched_tokens, "chunk": args.chunk},
+                       "max_num_batched_tokens": args.max_batched_tokens, "chunk": args.chunk,
+                       "pipelined_steps": not args.sync_steps},
             "requests_finished": finished, "slo_attainment": round(good / max(finished, 1), 4),
             "goodput_interactive_req_per_s": round(sum(s["good_interactive"] for s in allstats) / T, 3),
             "request_throughput": round(finished / T, 3),

@@ -132,6 +132,8 @@ class EngineConfig:
     device: str = "auto"                    # "auto" | "cuda" | "cpu"
     seed: int = 0
     use_hip_graphs: bool = True
+    # pipelined stepping: queue step N+1 while step N runs (None → on for GPU engines, off on CPU)
+    async_scheduling: Optional[bool] = None
     graph_batch_sizes: tuple = (1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
     weights_path: Optional[str] = None      # safetensors dir/file; None → random init
     tokenizer_path: Optional[str] = None    # HF tokenizer.json; None → byte-level tokenizer

@@ -210,4 +210,20 @@ void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int
                        temperature, top_p, top_k, seeds, steps, noise, out);
 }
 
+// Pipelined stepping: a decode row whose input id was sampled by the step still in flight reads it from the
+// sampler's device output (``src`` = row there, -1 = the host already staged the id).
+__global__ void gather_sampled_kernel(int* __restrict__ input, const int* __restrict__ src,
+                                      const int64_t* __restrict__ sampled, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int s = src[i];
+    if (s >= 0) input[i] = (int)sampled[s];
+  }
+}
+
+void launch_gather_sampled(int* input, const int* src, const int64_t* sampled, int n, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_sampled_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, input, src, sampled, n);
+}
+
 }  // namespace dli

@@ -160,6 +160,16 @@ void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const T
                      steps.data_ptr<int64_t>(), nz, out.data_ptr<int64_t>(), cur_stream(logits));
 }
 
+void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
+  TORCH_CHECK(input.is_cuda() && src.is_cuda() && sampled.is_cuda());
+  TORCH_CHECK(input.scalar_type() == at::kInt && src.scalar_type() == at::kInt && sampled.scalar_type() == at::kLong);
+  TORCH_CHECK(input.is_contiguous() && src.is_contiguous() && sampled.is_contiguous() && src.numel() >= input.numel());
+  // every src entry is a row of the previous step's sampler output: < sampled.numel() by construction of the
+  // scheduler (checked on the host in ModelRunner._stage)
+  dli::launch_gather_sampled(input.data_ptr<int>(), src.data_ptr<int>(), sampled.data_ptr<int64_t>(), (int)input.numel(),
+                             cur_stream(input));
+}
+
 // ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
                  int64_t expert_offset) {
@@ -267,6 +277,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("paged_attention_prefill(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, Tensor seq_lens, "
         "Tensor query_start_loc, Tensor tile_seq, Tensor tile_q0, int num_tiles, int num_heads, int num_kv_heads, float scale, "
         "float k_scale, float v_scale) -> ()", &paged_attention_prefill);
+  m.def("gather_sampled(Tensor(a!) input, Tensor src, Tensor sampled) -> ()", &gather_sampled);
   m.def("sample(Tensor(a!) out, Tensor logits, Tensor temperature, Tensor top_p, Tensor top_k, Tensor seeds, Tensor steps, "
         "Tensor? noise) -> ()", &sample);
 }

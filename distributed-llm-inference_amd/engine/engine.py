@@ -36,6 +36,8 @@ class LLMEngine:
         self.metrics = EngineMetrics()
         self.requests: dict[str, Request] = {}
         self._seq_ids = itertools.count(1)
+        self._inflight = None
+        self.async_scheduling = (self.runner.on_gpu if cfg.async_scheduling is None else bool(cfg.async_scheduling))
         if self.ctx.is_driver:
             self.bm = BlockManager(self.runner.num_blocks, KV_BLOCK_SIZE, cfg.cache.enable_prefix_caching)
             self.scheduler = Scheduler(cfg.sched, self.bm)
@@ -68,12 +70,12 @@ class LLMEngine:
         req = self.requests.pop(req_id, None)
         if req is None:
             return False
-        self.scheduler.abort(req_id)
+        self.scheduler.abort(req_id, req)
         self.metrics.on_finish(req, aborted=True)
         return True
 
     def has_unfinished(self) -> bool:
-        return self.scheduler.has_work()
+        return self.scheduler.has_work() or self._inflight is not None
 
     @property
     def num_running(self) -> int:
@@ -92,23 +94,44 @@ class LLMEngine:
 
     # ------------------------------------------------------------------ one step
     def step(self) -> list[RequestOutput]:
+        """One engine iteration.
+
+        Pipelined (``cfg.async_scheduling``, the GPU default): schedule and queue step N+1 *behind* the
+        step N still running on the GPU, then wait for step N's sampled ids and turn them into outputs —
+        scheduling, batch staging and output processing all run while the GPU is busy, and the stream never
+        drains between steps.  Ids the host has not seen yet are fed from the sampler's device buffer
+        (``ops.gather_sampled``); an EOS discovered one step late costs one discarded token.
+        Unpipelined: schedule → run → wait → outputs, nothing in flight between calls."""
         t0 = time.perf_counter()
         with trace_range("schedule"):
             batch = self.scheduler.schedule()
-        if batch is None:
-            return []
         t1 = time.perf_counter()
-        for r in batch.requests:
-            if r.first_scheduled is None:
-                r.first_scheduled = t1
-        if self.ctx.tp_size > 1 and self.metrics.steps % 128 == 0:
-            from ..runtime.tp_launcher import check_children
-            check_children()                                 # a dead TP worker would hang the next collective
-        with trace_range(f"execute[T={batch.total_tokens},B={len(batch.requests)}]"):
-            sampled = self.runner.execute(batch, self.bm)
+        launched = None
+        if batch is not None:
+            for r in batch.requests:
+                if r.first_scheduled is None:
+                    r.first_scheduled = t1
+            if self.ctx.tp_size > 1 and self.metrics.steps % 128 == 0:
+                from ..runtime.tp_launcher import check_children
+                check_children()                             # a dead TP worker would hang the next collective
+            with trace_range(f"launch[T={batch.total_tokens},B={len(batch.requests)}]"):
+                handle = self.runner.launch(batch, self.bm)
+                self.scheduler.advance(batch, self.cfg.sched.max_model_len)
+            launched = (batch, handle, t1 - t0, t1)
+        if self.async_scheduling:
+            prev, self._inflight = self._inflight, launched
+        else:
+            prev = launched
+        return self._finish_step(prev) if prev is not None else []
+
+    def _finish_step(self, inflight) -> list[RequestOutput]:
+        batch, handle, sched_s, t_launch = inflight
+        t1 = time.perf_counter()
+        with trace_range("collect"):
+            sampled = self.runner.collect(handle)
         t2 = time.perf_counter()
         with trace_range("update"):
-            results = self.scheduler.update(batch, sampled, self.cfg.model.eos_token_id, self.cfg.sched.max_model_len)
+            results = self.scheduler.resolve(batch, sampled, self.cfg.model.eos_token_id)
         outs = []
         for req, tok, status in results:
             if tok is None:
@@ -123,7 +146,8 @@ class LLMEngine:
                 self.metrics.on_finish(req)
             outs.append(RequestOutput(req.req_id, [tok], fin, status.value if fin else None, req.num_prompt,
                                       req.num_output, req.num_cached_prompt, req.client_tag))
-        self.metrics.on_step(batch, t1 - t0, t2 - t1, time.perf_counter() - t2, self)
+        # exec = launch → ids on the host (GPU time of the step as the caller sees it)
+        self.metrics.on_step(batch, sched_s, t2 - t_launch, time.perf_counter() - t2, self)
         return outs
 
     # ------------------------------------------------------------------ conveniences

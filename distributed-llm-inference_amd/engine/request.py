@@ -26,11 +26,12 @@ class RequestStatus(enum.Enum):
 
 class Request:
     """One generation request.  ``tokens[:num_tokens]`` = prompt + generated ids; ``num_computed`` of
-    them have their K/V in the paged cache."""
+    them have their K/V in the paged cache (or written by a step already queued on the stream)."""
 
     __slots__ = ("req_id", "seq_id", "params", "tokens", "num_prompt", "num_tokens", "num_computed", "status",
                  "arrival", "first_scheduled", "first_token_time", "finish_time", "num_cached_prompt",
-                 "preemptions", "seed", "client_tag", "last_token_time", "token_times")
+                 "preemptions", "seed", "client_tag", "last_token_time", "token_times", "pending", "sample_row",
+                 "finishing")
 
     def __init__(self, req_id: str, seq_id: int, prompt_ids, params: SamplingParams, arrival: Optional[float] = None,
                  client_tag=None):
@@ -55,6 +56,11 @@ class Request:
         self.seed = params.seed if params.seed is not None else (hash(req_id) & 0x7FFFFFFF)
         self.client_tag = client_tag
         self.token_times = None
+        # pipelined stepping: sampled tokens still in flight on the GPU.  They are already counted in
+        # ``num_tokens`` (placeholder id -1) so that the next step can be scheduled before they are known.
+        self.pending = 0
+        self.sample_row = -1            # row of this request in the in-flight step's sampler output
+        self.finishing = False          # length limit reached at launch time; finishes when resolved
 
     @property
     def num_output(self) -> int:
@@ -71,6 +77,11 @@ class Request:
     def append(self, tok: int) -> None:
         self.tokens[self.num_tokens] = tok
         self.num_tokens += 1
+
+    @property
+    def num_known(self) -> int:
+        """Tokens whose ids the host knows (everything except in-flight placeholders)."""
+        return self.num_tokens - self.pending
 
 
 @dataclass

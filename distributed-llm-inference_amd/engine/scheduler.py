@@ -43,13 +43,16 @@ class Scheduler:
     def add(self, req: Request) -> None:
         self.waiting.append(req)
 
-    def abort(self, req_id: str) -> Optional[Request]:
+    def abort(self, req_id: str, req: Optional[Request] = None) -> Optional[Request]:
         for q in (self.running, self.waiting):
             for r in q:
                 if r.req_id == req_id:
                     q.remove(r)
                     self._release(r, RequestStatus.FINISHED_ABORTED)
                     return r
+        if req is not None and req.finishing and not req.status.finished:
+            self._release(req, RequestStatus.FINISHED_ABORTED)     # out of the queues, last token in flight
+            return req
         return None
 
     def has_work(self) -> bool:
@@ -60,10 +63,14 @@ class Scheduler:
         req.status = status
 
     def finish(self, req: Request, status: RequestStatus) -> None:
-        if req in self.running:
-            self.running.remove(req)
+        if not req.finishing:
+            if req in self.running:
+                self.running.remove(req)
+            elif req in self.waiting:                      # preempted while its last step was in flight
+                self.waiting.remove(req)
         # publish the generated text too: the next turn of a conversation re-sends it as a prefix
-        self.bm.commit(req.seq_id, req.all_ids, req.num_computed)
+        if self.bm.has_seq(req.seq_id):
+            self.bm.commit(req.seq_id, req.all_ids, min(req.num_computed, req.num_tokens))
         self._release(req, status)
 
     def _preempt(self, req: Request) -> None:
@@ -135,30 +142,63 @@ class Scheduler:
         sample_mask = np.fromiter((r.num_computed + n == r.num_tokens for r, n in picked), dtype=bool, count=len(picked))
         return ScheduledBatch(reqs, num_new, num_decode, int(num_new.sum()), sample_mask, preempted)
 
-    # ------------------------------------------------------------------ after the forward pass
-    def update(self, batch: ScheduledBatch, sampled: np.ndarray, eos_token_id: int, max_model_len: int):
-        """Advance the scheduled sequences; returns ``[(request, new_token or None, finished_status or None)]``."""
-        out = []
+    # ------------------------------------------------------------------ around the forward pass
+    # A step is accounted for in two halves so that step N+1 can be scheduled and queued on the GPU
+    # while step N is still running (pipelined stepping, SURVEY.md §7.3 item 5 "CPU overhead"):
+    #   advance(batch)  – at launch: the KV of the scheduled tokens is as good as written (everything
+    #                     later is ordered behind it on the stream); a sampled token is counted right away
+    #                     as a placeholder, and a length limit reached by it takes the request out of
+    #                     scheduling;
+    #   resolve(batch…) – when the sampled ids arrive: fill the placeholders, detect EOS/stop tokens, finish.
+    # An EOS found by resolve(N) may come after step N+1 was queued with the same request in it; that
+    # step's extra token is dropped (the request is already finished when it resolves).
+    def advance(self, batch: ScheduledBatch, max_model_len: int) -> None:
         j = 0
         for req, n_new, samples in zip(batch.requests, batch.num_new, batch.sample_mask):
             req.num_computed += int(n_new)
-            tok = None
-            status = None
             if samples:
-                tok = int(sampled[j])
+                if req.num_computed - n_new < req.num_prompt:   # this step completes the prompt: publish its pages
+                    self.bm.commit(req.seq_id, req.tokens[:req.num_prompt], req.num_prompt)
+                req.sample_row = j
                 j += 1
-                req.append(tok)
-                p = req.params
-                if (not p.ignore_eos) and (tok == eos_token_id or tok in p.stop_token_ids):
-                    status = RequestStatus.FINISHED_STOPPED
-                elif req.num_output >= p.max_tokens or req.num_tokens >= max_model_len:
-                    status = RequestStatus.FINISHED_LENGTH
+                req.append(-1)
+                req.pending += 1
+                if req.num_output >= req.params.max_tokens or req.num_tokens >= max_model_len:
+                    req.finishing = True
+                    self.running.remove(req)               # holds its pages until the token arrives
             elif req.num_computed % (8 * self.bm.block_size) < n_new:
                 # a long prefill crossed a multiple of 8 pages: publish its full pages early
-                self.bm.commit(req.seq_id, req.all_ids, req.num_computed)
-            if req.num_computed == req.num_prompt and samples:
-                self.bm.commit(req.seq_id, req.all_ids, req.num_computed)     # prompt complete
+                self.bm.commit(req.seq_id, req.tokens[:req.num_prompt], min(req.num_computed, req.num_prompt))
+
+    def resolve(self, batch: ScheduledBatch, sampled: np.ndarray, eos_token_id: int):
+        """Returns ``[(request, new_token or None, finished_status or None)]`` for the step's sequences."""
+        out = []
+        j = 0
+        for req, samples in zip(batch.requests, batch.sample_mask):
+            if not samples:
+                out.append((req, None, None))
+                continue
+            tok = int(sampled[j])
+            j += 1
+            if req.status.finished:                         # stopped/aborted while this step was in flight
+                continue
+            pos = req.num_tokens - req.pending
+            req.tokens[pos] = tok
+            req.pending -= 1
+            status = None
+            p = req.params
+            if (not p.ignore_eos) and (tok == eos_token_id or tok in p.stop_token_ids):
+                status = RequestStatus.FINISHED_STOPPED
+                req.num_tokens = pos + 1                    # drop the placeholder of a step queued behind
+                req.pending = 0
+            elif req.finishing and req.pending == 0:
+                status = RequestStatus.FINISHED_LENGTH
             if status is not None:
                 self.finish(req, status)
             out.append((req, tok, status))
         return out
+
+    def update(self, batch: ScheduledBatch, sampled: np.ndarray, eos_token_id: int, max_model_len: int):
+        """Both halves back to back (unpipelined stepping)."""
+        self.advance(batch, max_model_len)
+        return self.resolve(batch, sampled, eos_token_id)

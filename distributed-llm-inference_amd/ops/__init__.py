@@ -181,6 +181,15 @@ def sample(logits: torch.Tensor, temperature: torch.Tensor, top_p: torch.Tensor,
     return res
 
 
+def gather_sampled(input_ids: torch.Tensor, src: torch.Tensor, sampled: torch.Tensor) -> None:
+    """In place: ``input_ids[i] = sampled[src[i]]`` where ``src[i] >= 0`` (pipelined stepping)."""
+    if input_ids.is_cuda:
+        hip().gather_sampled(input_ids, src, sampled)
+    else:
+        m = src >= 0
+        input_ids[m] = sampled[src[m].long()].to(input_ids.dtype)
+
+
 def copy_pages(cache: torch.Tensor, pairs: torch.Tensor) -> None:
     """Copy-on-write helper: ``cache[dst] = cache[src]`` for every ``(src, dst)`` row of ``pairs``."""
     if cache.is_cuda:

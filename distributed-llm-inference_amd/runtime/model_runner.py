@@ -102,14 +102,15 @@ class ModelRunner:
         max_tiles = T // 16 + B + 1
         fields = [("input", T), ("pos", T), ("slot", T), ("seq_lens", B), ("qsl", B + 1), ("last", B),
                   ("top_k", B), ("temp", B), ("top_p", B), ("seeds", 2 * B), ("steps", 2 * B),
-                  ("tile_seq", max_tiles), ("tile_q0", max_tiles), ("bt", B * self.max_blocks_per_seq)]
+                  ("src", B), ("tile_seq", max_tiles), ("tile_q0", max_tiles), ("bt", B * self.max_blocks_per_seq)]
         self.layout, off = {}, 0
         for name, n in fields:
             off = (off + 3) // 4 * 4                      # 16-byte aligned regions
             self.layout[name] = (off, n)
             off += n
         total = (off + 3) // 4 * 4
-        self.h_buf = _pinned(total, torch.int32, self.on_gpu)
+        # two host copies: step N+1 is staged while the H2D copy of step N may still be queued
+        h_bufs = [_pinned(total, torch.int32, self.on_gpu) for _ in range(2)]
         self.d_buf = torch.zeros(total, dtype=torch.int32, device=self.device)
 
         def views(buf):
@@ -119,15 +120,27 @@ class ModelRunner:
             v["bt"] = v["bt"].view(B, self.max_blocks_per_seq)
             return v
 
-        self.hv, self.dv = views(self.h_buf), views(self.d_buf)
-        self.nv = {k: t.numpy() for k, t in self.hv.items()}
-        self.n_input, self.n_pos, self.n_slot = self.nv["input"], self.nv["pos"], self.nv["slot"]
-        self.n_bt, self.n_seq_lens, self.n_qsl = self.nv["bt"], self.nv["seq_lens"], self.nv["qsl"]
+        self.dv = views(self.d_buf)
+        self._host_sets = []
+        for hb in h_bufs:
+            hv = views(hb)
+            self._host_sets.append((hb, hv, {k: t.numpy() for k, t in hv.items()}))
+        self._host_idx = 0
+        self._bind_host(0)
         self.d_sampled = torch.zeros(B, dtype=torch.int64, device=self.device)
-        self.h_sampled = _pinned(B, torch.int64, self.on_gpu)
+        self.h_sampled = [_pinned(B, torch.int64, self.on_gpu) for _ in range(2)]
+        self._fetch_idx = 0
+        self._prev_event = None
         max_splits = 16
         self.decode_ws = (torch.empty(B * self.local_heads * max_splits * 130, dtype=torch.float32, device=self.device)
                           if self.on_gpu else None)
+
+    def _bind_host(self, i: int):
+        self._host_idx = i
+        self.h_buf, self.hv, self.nv = self._host_sets[i]
+        nv = self.nv
+        self.n_input, self.n_pos, self.n_slot = nv["input"], nv["pos"], nv["slot"]
+        self.n_bt, self.n_seq_lens, self.n_qsl = nv["bt"], nv["seq_lens"], nv["qsl"]
 
     # ------------------------------------------------------------------ batch → device
     def _stage(self, batch, bm):
@@ -138,8 +151,14 @@ class ModelRunner:
         computed = np.fromiter((r.num_computed for r in reqs), dtype=np.int32, count=B)
         bm.build_batch(seq_ids, computed, batch.num_new, self.n_pos, self.n_slot, self.n_bt, self.n_seq_lens, self.n_qsl)
         nd = batch.num_decode
+        n_src = 0
         if nd:
             self.n_input[:nd] = np.fromiter((r.tokens[r.num_computed] for r in reqs[:nd]), dtype=np.int32, count=nd)
+            # ids still on the GPU (sampled by the step in flight): row of the previous sampler output
+            src = nv["src"][:nd]
+            src[:] = np.fromiter((r.sample_row if r.pending else -1 for r in reqs[:nd]), dtype=np.int32, count=nd)
+            n_src = int((src >= 0).sum())
+            assert n_src == int((self.n_input[:nd] < 0).sum()), "in-flight token bookkeeping out of sync"
         off = nd
         for r, n in zip(reqs[nd:], batch.num_new[nd:]):
             self.n_input[off:off + n] = r.tokens[r.num_computed:r.num_computed + n]
@@ -160,7 +179,7 @@ class ModelRunner:
             n_tiles = len(ts)
             nv["tile_seq"][:n_tiles] = ts
             nv["tile_q0"][:n_tiles] = t0
-        return B, T, S, n_tiles
+        return B, T, S, n_tiles, n_src
 
     def _copy_in(self):
         self.d_buf.copy_(self.h_buf, non_blocking=True)
@@ -185,10 +204,12 @@ class ModelRunner:
                    out=self.d_sampled[:S])
 
     @torch.inference_mode()
-    def execute(self, batch, bm) -> np.ndarray:
-        """Driver-side step: stage the batch, (broadcast it to the TP workers,) run it; returns the
-        sampled token ids (one per ``sample_mask`` row)."""
-        B, T, S, n_tiles = self._stage(batch, bm)
+    def launch(self, batch, bm):
+        """Driver-side first half of a step: stage the batch, (broadcast it to the TP workers,) queue the
+        forward pass, the sampler and the D2H copy of the sampled ids.  Returns a handle for ``collect``.
+        At most one earlier step may still be uncollected (its sampled ids are then read on the device)."""
+        self._bind_host(self._host_idx ^ 1)
+        B, T, S, n_tiles, n_src = self._stage(batch, bm)
         nd = batch.num_decode
         bucket = 0
         if nd == B and S == B and self.on_gpu and self.cfg.use_hip_graphs:
@@ -196,17 +217,29 @@ class ModelRunner:
         splits = 1
         if self.on_gpu and nd and not bucket:
             splits = ops.choose_decode_splits(nd, self.local_kv_heads, int(self.n_seq_lens[:nd].max()))
-        header = (B, T, S, nd, n_tiles, bucket, splits)
+        header = (B, T, S, nd, n_tiles, bucket, splits, n_src)
         if self.ctx.tp_size > 1:
             self._broadcast_step(header)
         return self.run_staged(header)
 
+    def collect(self, handle) -> np.ndarray:
+        """Second half: wait for the step's sampled token ids (one per ``sample_mask`` row)."""
+        kind, a, b = handle
+        if kind == "host":
+            return a
+        a.synchronize()                                      # the event recorded behind the D2H copy
+        buf, n = b
+        return buf.numpy()[:n].copy()
+
+    def execute(self, batch, bm) -> np.ndarray:
+        return self.collect(self.launch(batch, bm))
+
     def _broadcast_step(self, header):
-        """Driver → workers: 7-int header over the CPU (gloo) group, packed step buffer over the
+        """Driver → workers: 8-int header over the CPU (gloo) group, packed step buffer over the
         device group (RCCL broadcast of a few hundred KB)."""
         import torch.distributed as dist
         ctx = self.ctx
-        hdr = torch.tensor(header if header is not None else (-1,) * 7, dtype=torch.int64)
+        hdr = torch.tensor(header if header is not None else (-1,) * 8, dtype=torch.int64)
         g = ctx.cpu_group if ctx.cpu_group is not None else ctx.group
         dist.broadcast(hdr, src=dist.get_global_rank(g, 0), group=g)
         if int(hdr[0]) < 0:
@@ -223,48 +256,57 @@ class ModelRunner:
         header = self._broadcast_step(None)
         if header is None:
             return False
-        self.run_staged(header, staged_on_device=True)
+        _kind, ev, _ = self.run_staged(header, staged_on_device=True)
+        if self._prev_event is not None:                     # stay at most one step ahead of the GPU, like the driver
+            self._prev_event.synchronize()
+        self._prev_event = ev if _kind == "event" else None
         return True
 
     def shutdown_workers(self):
         if self.ctx.tp_size > 1 and self.ctx.is_driver:
             import torch.distributed as dist
             g = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
-            dist.broadcast(torch.full((7,), -1, dtype=torch.int64), src=dist.get_global_rank(g, 0), group=g)
+            dist.broadcast(torch.full((8,), -1, dtype=torch.int64), src=dist.get_global_rank(g, 0), group=g)
 
     def _pad_for(self, header):
-        B, _T, _S, _nd, _nt, bucket, _sp = header
+        B, bucket = header[0], header[5]
         if bucket:
             self._pad_decode(B, bucket)
 
     @torch.inference_mode()
-    def run_staged(self, header, staged_on_device: bool = False) -> np.ndarray:
-        B, T, S, nd, n_tiles, bucket, splits = header
+    def run_staged(self, header, staged_on_device: bool = False):
+        B, T, S, nd, n_tiles, bucket, splits, n_src = header
         tp_staged = self.ctx.tp_size > 1                    # _broadcast_step already padded + copied
+        if bucket and not tp_staged:
+            self._pad_decode(B, bucket)
+        if not tp_staged:
+            self._copy_in()
+        if n_src:
+            # decode rows whose input id was sampled by the step still in flight: take it from the sampler's
+            # device output (stream order puts this behind that step and ahead of this step's sampler)
+            ops.gather_sampled(self.dv["input"][:nd], self.dv["src"][:nd], self.d_sampled)
         if bucket:
-            if not tp_staged:
-                self._pad_decode(B, bucket)
-                self._copy_in()
             if bucket not in self.graphs:
                 self.capture_graph(bucket)
             self.graphs[bucket][0].replay()
             self.stats["graph_steps"] += 1
             return self._fetch(B)
-        if not tp_staged:
-            self._copy_in()
         meta = self._meta(B, T, nd, 0, splits, n_tiles)
         self._forward_sample(T, S, meta)
         self.stats["eager_steps"] += 1
         return self._fetch(S)
 
-    def _fetch(self, S) -> np.ndarray:
-        if S == 0:
-            return np.zeros(0, dtype=np.int64)
-        if self.on_gpu:
-            self.h_sampled[:S].copy_(self.d_sampled[:S], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            return self.h_sampled.numpy()[:S].copy()
-        return self.d_sampled[:S].numpy().copy()
+    def _fetch(self, S):
+        """Queue the D2H copy of the sampled ids; the handle is resolved by ``collect``."""
+        if not self.on_gpu:
+            return ("host", self.d_sampled[:S].numpy().copy(), None)
+        self._fetch_idx ^= 1
+        buf = self.h_sampled[self._fetch_idx]
+        if S:
+            buf[:S].copy_(self.d_sampled[:S], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ("event", ev, (buf, S))
 
     # ------------------------------------------------------------------ hipGraph decode
     def _bucket_for(self, B: int) -> Optional[int]:
@@ -288,6 +330,7 @@ class ModelRunner:
             nv["temp"][B:bucket] = 0.0
             nv["top_p"][B:bucket] = 1.0
             nv["top_k"][B:bucket] = 0
+            nv["src"][B:bucket] = -1
 
     def capture_graph(self, bucket: int):
         """Capture one decode step at batch size ``bucket`` (inputs must be staged in the static buffers)."""

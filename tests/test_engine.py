@@ -201,3 +201,72 @@ def test_build_batch_layout():
     assert bt[0, :2].tolist() == t7 and bt[1, :3].tolist() == t9
     with pytest.raises(RuntimeError):
         bm.build_batch(np.array([7]), np.array([39], np.int32), np.array([30], np.int32), pos, slot, bt, sl, qs)
+
+
+# ------------------------------------------------------------------ pipelined (async) stepping
+def _run_workload(async_mode, num_blocks=64, stop=(), max_seqs=8, budget=64, abort_at=None):
+    eng = make_engine(num_blocks=num_blocks, max_tokens=budget, max_seqs=max_seqs, chunk=32, prefix=True,
+                      async_scheduling=async_mode)
+    assert eng.async_scheduling == async_mode
+    rng = np.random.default_rng(11)
+    reqs = {}
+    arrivals = {0: [0, 1, 2], 2: [3], 3: [4, 5], 9: [6], 15: [7, 8, 9]}
+    lens = [5, 70, 33, 1, 100, 64, 31, 12, 90, 40]
+    outs = {i: [] for i in range(10)}
+    fins = {}
+    step = 0
+    while step < 400:
+        for i in arrivals.get(step, ()):
+            greedy = i % 2 == 0
+            p = SamplingParams(temperature=0.0 if greedy else 0.9, top_k=0 if greedy else 40, max_tokens=6 + 3 * i,
+                               seed=100 + i, stop_token_ids=tuple(stop), ignore_eos=False)
+            reqs[i] = eng.add_request(f"r{i}", prompt_ids=rng.integers(3, 500, size=lens[i]).tolist(), params=p)
+        if abort_at is not None and step == abort_at:
+            assert eng.abort_request("r1")
+        if step > 15 and not eng.has_unfinished():
+            break
+        for o in eng.step():
+            i = int(o.req_id[1:])
+            outs[i].extend(o.new_token_ids)
+            if o.finished:
+                assert i not in fins
+                fins[i] = (o.finish_reason, o.num_output_tokens)
+        step += 1
+    assert not eng.has_unfinished() and eng.bm.num_free == eng.bm.num_blocks
+    for i, r in reqs.items():
+        if i in fins:
+            assert r.pending == 0 and r.output_ids.tolist() == outs[i] and fins[i][1] == len(outs[i])
+            assert (r.tokens[:r.num_tokens] >= 0).all()
+    return outs, fins, eng
+
+
+def test_pipelined_stepping_equals_unpipelined():
+    a_out, a_fin, a_eng = _run_workload(False)
+    b_out, b_fin, b_eng = _run_workload(True)
+    assert a_out == b_out and a_fin == b_fin and len(a_fin) == 10
+    assert sum(reason == "length" for reason, _ in a_fin.values()) >= 5
+    # same forward passes, plus at most one extra per EOS that was discovered a step late
+    assert a_eng.metrics.steps <= b_eng.metrics.steps <= a_eng.metrics.steps + 5
+
+
+def test_pipelined_stepping_stop_tokens_are_found_one_step_late_but_output_is_identical():
+    base, _, _ = _run_workload(False)
+    # pick tokens that really occur mid-generation so that several requests stop early
+    stop = sorted({base[i][len(base[i]) // 2] for i in (1, 4, 7, 8)})
+    a_out, a_fin, _ = _run_workload(False, stop=stop)
+    b_out, b_fin, b_eng = _run_workload(True, stop=stop)
+    assert a_out == b_out and a_fin == b_fin
+    assert sum(reason == "stop" for reason, _ in a_fin.values()) >= 3
+    for i, (reason, _n) in a_fin.items():
+        if reason == "stop":
+            assert a_out[i][-1] in stop and not (set(a_out[i][:-1]) & set(stop))
+
+
+def test_pipelined_stepping_with_preemption_and_abort():
+    a_out, a_fin, a_eng = _run_workload(False, num_blocks=9, abort_at=6)
+    b_out, b_fin, b_eng = _run_workload(True, num_blocks=9, abort_at=6)
+    assert a_eng.scheduler.num_preemptions > 0 and b_eng.scheduler.num_preemptions > 0
+    assert 1 not in a_fin and 1 not in b_fin
+    for i in a_fin:
+        assert a_out[i] == b_out[i] and a_fin[i] == b_fin[i]
+    assert set(a_fin) == set(b_fin) == set(range(10)) - {1}

@@ -12,8 +12,8 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(model, tp, ep, prompts):
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+def run(model, tp, ep, prompts, pipelined=False):
+    env = dict(os.environ, OMP_NUM_THREADS="2", DLI_TEST_ASYNC="1" if pipelined else "0")
     p = subprocess.run([sys.executable, os.path.join(HERE, "tp_script.py"), model, str(tp), str(ep), json.dumps(prompts)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -40,3 +40,10 @@ def test_tp_matches_single_rank(model, tp, ep):
     got = run(model, tp, ep, prompts())
     assert got["greedy"] == want["greedy"]
     assert got["sampled"] == want["sampled"]
+
+
+def test_tp_pipelined_stepping_matches_single_rank():
+    """Driver queues step N+1 before step N's ids are known; the workers feed their own sampler output."""
+    want = run("tiny-llama", 1, 1, prompts())
+    got = run("tiny-llama", 2, 1, prompts(), pipelined=True)
+    assert got == want
