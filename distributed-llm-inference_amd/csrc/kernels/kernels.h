@@ -37,9 +37,10 @@ void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int
                       int capacity_rows, hipStream_t stream);
 void launch_grouped_gemm(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
                          const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
-                         void* out, int64_t out_stride, int K, int N_out, int max_tiles, hipStream_t stream);
-void launch_moe_sum(const void* y, const int* ids, int expert_offset, int E_local, int top_k, int T, int H, void* out,
-                    hipStream_t stream);
+                         void* out, int64_t out_stride, int K, int N_out, int max_tiles, int k_splits, int64_t slab_elems,
+                         hipStream_t stream);
+void launch_moe_sum(const void* y, bool y_fp32, int n_slabs, int64_t slab_elems, const int* ids, int expert_offset, int E_local,
+                    int top_k, int T, int H, void* out, hipStream_t stream);
 
 // custom all-reduce over IPC-mapped peer buffers (custom_all_reduce.hip)
 void* ar_alloc(size_t bytes, bool uncached);

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------ grouped GEMM
-enum { EPI_SWIGLU = 0, EPI_SCATTER = 1 };
+enum { EPI_SWIGLU = 0, EPI_SCATTER = 1, EPI_SCATTER_SPLITK = 2 };   // SPLITK: fp32 partial slabs, summed by moe_sum
 
 // byte offset of 16-byte chunk c (0..7) of row r inside a [128][64] bf16 LDS tile, XOR-swizzled so that
 // the 16 rows a ds_read_b128 lane group touches fall on different bank groups
@@ -101,15 +101,36 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
     const uint16_t* __restrict__ A, int64_t a_stride,         // EPI_SWIGLU: x [T, K], rows gathered; EPI_SCATTER: act [P, K]
     const uint16_t* __restrict__ W, int64_t w_expert_stride,  // [E_local, N_total, K]
     const int* __restrict__ sorted_ids, const int* __restrict__ tile_expert, const int* __restrict__ meta,
-    const float* __restrict__ topk_w, int top_k, uint16_t* __restrict__ out, int64_t out_stride, int K, int N_half) {
+    const float* __restrict__ topk_w, int top_k, void* __restrict__ out_, int64_t out_stride, int K, int N_half,
+    int n_col_blocks, int k_splits, int64_t slab_elems) {
+  uint16_t* out = reinterpret_cast<uint16_t*>(out_);
   __shared__ __attribute__((aligned(16))) char lds[2 * BM * BK * 2];
   char* ldsA = lds;
   char* ldsB = lds + BM * BK * 2;
-  const int tile = blockIdx.x;
-  if (tile >= meta[0]) return;
+  // ---- block → (row tile, column block), XCD-aware.  The hardware deals workgroups round-robin over the 8
+  // XCDs (id % 8), each with a private 4 MB L2.  Work is cut into super-tiles of 8 row tiles × 8 column
+  // blocks; XCD k runs super-tiles k, k+8, …, 64 consecutive workgroups each, so the blocks resident on
+  // one XCD at a time share 8 A tiles and (row tiles being sorted by expert) 8–16 W tiles: each operand
+  // K-slice is fetched into that L2 once and reused 8×, instead of every block streaming a private
+  // 1 MB W tile from HBM (the round-robin default puts the 8 row tiles of an expert on 8 different XCDs).
+  // With fewer than 8 row tiles (decode-sized batches) the super-tile narrows to 4/2/1 row tiles × 16/32/64
+  // column blocks, so that the live blocks still spread over all XCDs.
+  const int n_tiles = meta[0];
+  const int gx_log = n_tiles >= 5 ? 3 : n_tiles >= 3 ? 2 : n_tiles >= 2 ? 1 : 0;
+  const int gy_log = 6 - gx_log;
+  const int j = blockIdx.x >> 3;
+  const int super = (j >> 6) * 8 + (blockIdx.x & 7);
+  const int n_virtual = n_col_blocks * k_splits;             // split-K slices are extra "columns" (slowest index)
+  const int sy_count = (n_virtual + (1 << gy_log) - 1) >> gy_log;
+  const int sx = super / sy_count, sy = super - sx * sy_count;
+  const int tile = (sx << gx_log) + (j & ((1 << gx_log) - 1));
+  const int col_virtual = (sy << gy_log) + ((j & 63) >> gx_log);
+  if (tile >= n_tiles || col_virtual >= n_virtual) return;
+  const int split = col_virtual / n_col_blocks;
+  const int col_block = col_virtual - split * n_col_blocks;
   const int e = tile_expert[tile];
   const uint16_t* We = W + (int64_t)e * w_expert_stride;
-  const int n0 = blockIdx.y * (EPI == EPI_SWIGLU ? BN / 2 : BN);   // SWIGLU: 64 output columns per tile
+  const int n0 = col_block * (EPI == EPI_SWIGLU ? BN / 2 : BN);   // SWIGLU: 64 output columns per tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int col = lane & 15, g = lane >> 4;
@@ -146,14 +167,17 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // this block's K-steps: slice `split` of k_splits (contiguous, sizes differ by at most one step)
+  const int nk_total = K / BK;
+  const int kt0 = (int)((int64_t)nk_total * split / k_splits);
+  const int nk = (int)((int64_t)nk_total * (split + 1) / k_splits);
   bf16x8 pa[4], pb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    pa[i] = *reinterpret_cast<const bf16x8*>(a_src[i]);
-    pb[i] = *reinterpret_cast<const bf16x8*>(b_src[i]);
+    pa[i] = *reinterpret_cast<const bf16x8*>(a_src[i] + kt0 * BK);
+    pb[i] = *reinterpret_cast<const bf16x8*>(b_src[i] + kt0 * BK);
   }
-  const int nk = K / BK;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     __syncthreads();                                           // previous tile fully consumed
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -202,6 +226,18 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
         }
         *reinterpret_cast<bf16x4*>(dst + n * 16) = o;           // padding rows hold finite junk, never read back
       }
+    } else if (EPI == EPI_SCATTER_SPLITK) {
+      if (sid >= 0) {
+        const float w = topk_w[sid];
+        float* dst = reinterpret_cast<float*>(out_) + split * slab_elems + (int64_t)sid * out_stride + n0 + wn * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = acc[m][n][r] * w;
+          *reinterpret_cast<f32x4*>(dst + n * 16) = o;
+        }
+      }
     } else if (sid >= 0) {
       const float w = topk_w[sid];
       uint16_t* dst = out + (int64_t)sid * out_stride + n0 + wn * 64 + 4 * g;
@@ -217,18 +253,31 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
 }
 
 // ------------------------------------------------------------------------------------------ un-permute
-__global__ __launch_bounds__(256) void moe_sum_kernel(const uint16_t* __restrict__ y, const int* __restrict__ ids,
-                                                      int expert_offset, int E_local, int top_k, int H,
-                                                      uint16_t* __restrict__ out) {
+// SLABS == 0: y is bf16 [T·k, H].  SLABS > 0 (runtime count in n_slabs): y is fp32 [n_slabs][T·k, H] split-K partials.
+template <bool F32>
+__global__ __launch_bounds__(256) void moe_sum_kernel(const void* __restrict__ y_, const int* __restrict__ ids,
+                                                      int expert_offset, int E_local, int top_k, int H, int n_slabs,
+                                                      int64_t slab_elems, uint16_t* __restrict__ out) {
   const int t = blockIdx.x;
   for (int v = threadIdx.x; v < H / 8; v += blockDim.x) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int s = 0; s < top_k; ++s) {
       const int e = ids[t * top_k + s] - expert_offset;
       if (e < 0 || e >= E_local) continue;
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(y + ((int64_t)t * top_k + s) * H + v * 8);
+      const int64_t row = ((int64_t)t * top_k + s) * H + v * 8;
+      if (F32) {
+        const float* y = reinterpret_cast<const float*>(y_);
+        for (int k = 0; k < n_slabs; ++k) {                 // fixed order: bitwise reproducible
+          const f32x4 a = *reinterpret_cast<const f32x4*>(y + k * slab_elems + row);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(y + k * slab_elems + row + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += bf2f((uint16_t)a[j]);
+          for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+        }
+      } else {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(y_) + row);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf2f((uint16_t)a[j]);
+      }
     }
     bf16x8 o;
 #pragma unroll
@@ -251,26 +300,32 @@ void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int
 
 void launch_grouped_gemm(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
                          const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
-                         void* out, int64_t out_stride, int K, int N_out, int max_tiles, hipStream_t stream) {
+                         void* out, int64_t out_stride, int K, int N_out, int max_tiles, int k_splits, int64_t slab_elems,
+                         hipStream_t stream) {
   if (max_tiles == 0) return;
-  if (epilogue == EPI_SWIGLU) {
-    dim3 grid(max_tiles, N_out / (BN / 2));
-    hipLaunchKernelGGL(grouped_gemm_kernel<EPI_SWIGLU>, grid, dim3(256), 0, stream, (const uint16_t*)A, a_stride,
-                       (const uint16_t*)W, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, (uint16_t*)out,
-                       out_stride, K, N_out);
-  } else {
-    dim3 grid(max_tiles, N_out / BN);
-    hipLaunchKernelGGL(grouped_gemm_kernel<EPI_SCATTER>, grid, dim3(256), 0, stream, (const uint16_t*)A, a_stride,
-                       (const uint16_t*)W, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, (uint16_t*)out,
-                       out_stride, K, N_out);
-  }
+  const int n_col_blocks = N_out / (epilogue == EPI_SWIGLU ? BN / 2 : BN);
+  const int n_virtual = n_col_blocks * k_splits;
+  const int supers = (max_tiles + 7) / 8 * ((n_virtual + 7) / 8);
+  dim3 grid((supers + 7) / 8 * 8 * 64);                                      // surplus blocks exit on meta[0]
+#define DLI_GG(EPI)                                                                                                       \
+  hipLaunchKernelGGL(grouped_gemm_kernel<EPI>, grid, dim3(256), 0, stream, (const uint16_t*)A, a_stride, (const uint16_t*)W, \
+                     w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, out_stride, K, N_out, n_col_blocks, \
+                     k_splits, slab_elems)
+  if (epilogue == EPI_SWIGLU) DLI_GG(EPI_SWIGLU);
+  else if (epilogue == EPI_SCATTER) DLI_GG(EPI_SCATTER);
+  else DLI_GG(EPI_SCATTER_SPLITK);
+#undef DLI_GG
 }
 
-void launch_moe_sum(const void* y, const int* ids, int expert_offset, int E_local, int top_k, int T, int H, void* out,
-                    hipStream_t stream) {
+void launch_moe_sum(const void* y, bool y_fp32, int n_slabs, int64_t slab_elems, const int* ids, int expert_offset, int E_local,
+                    int top_k, int T, int H, void* out, hipStream_t stream) {
   if (T == 0) return;
-  hipLaunchKernelGGL(moe_sum_kernel, dim3(T), dim3(256), 0, stream, (const uint16_t*)y, ids, expert_offset, E_local, top_k, H,
-                     (uint16_t*)out);
+  if (y_fp32)
+    hipLaunchKernelGGL(moe_sum_kernel<true>, dim3(T), dim3(256), 0, stream, y, ids, expert_offset, E_local, top_k, H, n_slabs,
+                       slab_elems, (uint16_t*)out);
+  else
+    hipLaunchKernelGGL(moe_sum_kernel<false>, dim3(T), dim3(256), 0, stream, y, ids, expert_offset, E_local, top_k, H, 1,
+                       slab_elems, (uint16_t*)out);
 }
 
 }  // namespace dli

@@ -1,6 +1,7 @@
 // torch.ops.dli.* — argument checking + stream plumbing around the HIP launchers in kernels/.
 // Every op launches on the *current* HIP stream, so the ops are capturable into hipGraphs
 // (torch.cuda.graph) without any host synchronisation (cdna guide §6 G9).
+#include <algorithm>
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
@@ -189,18 +190,26 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   const int64_t max_tiles = capacity / 128;
   Tensor ids = at::empty({n}, i32), wts = at::empty({n}, x.options().dtype(at::kFloat));
   Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
-  Tensor act = at::empty({capacity, I}, x.options()), y = at::empty({n, H}, x.options()), out = at::empty({T, H}, x.options());
+  Tensor act = at::empty({capacity, I}, x.options()), out = at::empty({T, H}, x.options());
+  // Down projection: with few row tiles (decode-sized batches) a (row tile × 128 columns) grid cannot fill 256 CUs and
+  // every block would stream a 3.7 MB weight panel through a 16 KB-deep pipeline, so K is cut into slices whose fp32
+  // partial slabs are summed (in fixed order) by moe_sum.  The slice count depends on T only: static under hipGraph.
+  const int64_t col_blocks2 = H / 128, nk2 = I / 64;
+  int64_t k_splits = 1;
+  if (max_tiles * col_blocks2 < 1024) k_splits = std::min<int64_t>({(1024 + max_tiles * col_blocks2 - 1) / (max_tiles * col_blocks2), 16, nk2});
+  const bool split = k_splits > 1;
+  Tensor y = split ? at::empty({k_splits, n, H}, x.options().dtype(at::kFloat)) : at::empty({n, H}, x.options());
   dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
   dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
                         tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, stream);
   dli::launch_grouped_gemm(0, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
                            meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, act.data_ptr(), I, (int)H, (int)I,
-                           (int)max_tiles, stream);
-  dli::launch_grouped_gemm(1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
-                           meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H, (int)I, (int)H,
-                           (int)max_tiles, stream);
-  dli::launch_moe_sum(y.data_ptr(), ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k, (int)T, (int)H, out.data_ptr(),
-                      stream);
+                           (int)max_tiles, 1, 0, stream);
+  dli::launch_grouped_gemm(split ? 2 : 1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(),
+                           tile_expert.data_ptr<int>(), meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H,
+                           (int)I, (int)H, (int)max_tiles, (int)k_splits, n * H, stream);
+  dli::launch_moe_sum(y.data_ptr(), split, (int)k_splits, n * H, ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k,
+                      (int)T, (int)H, out.data_ptr(), stream);
   return out;
 }
 

@@ -313,7 +313,7 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--num-kv-blocks", type=int, default=None)
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
     ap.add_argument("--no-prefix-caching", action="store_true")
-    ap.add_argument("--max-num-seqs", type=int, default=512)
+    ap.add_argument("--max-num-seqs", type=int, default=1024)
     ap.add_argument("--max-num-batched-tokens", type=int, default=4096)
     ap.add_argument("--max-model-len", type=int, default=4096)
     ap.add_argument("--max-position", type=int, default=None)

@@ -235,7 +235,8 @@ def test_copy_pages():
 
 
 @pytest.mark.parametrize("T,H,I,E,El,off", [(1, 512, 1024, 4, 4, 0), (300, 4096, 1792, 8, 8, 0), (77, 1024, 448, 8, 2, 4),
-                                             (1000, 512, 256, 8, 1, 3)])
+                                             (1000, 512, 256, 8, 1, 3),
+                                             (1500, 4096, 448, 8, 8, 0)])     # last: enough row tiles → no split-K
 def test_fused_moe_matches_reference(T, H, I, E, El, off):
     x = _bf(T, H, seed=41)
     logits = _bf(T, E, seed=42, scale=2.0)
