@@ -15,6 +15,8 @@ Messages from the core: ("out", [(req_id, token, finished, reason, n_prompt, n_o
 """
 from __future__ import annotations
 
+import os
+
 import asyncio
 import dataclasses
 import multiprocessing as mp
@@ -98,8 +100,11 @@ def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
     engine.shutdown()
 
 
-def _process_main(cfg: EngineConfig, conn, device_index: int):
+def _process_main(cfg: EngineConfig, conn, device_index: int, parent_pid: int = 0):
     try:
+        if parent_pid:                                       # never outlive the front end (it owns the clients)
+            from ..runtime.tp_launcher import _die_with_parent
+            _die_with_parent(parent_pid)
         import torch
         if torch.cuda.is_available() and cfg.device != "cpu":
             torch.cuda.set_device(device_index)
@@ -151,7 +156,7 @@ class AsyncEngine:
             parent, child = ctx.Pipe(duplex=True)
             self._chan = parent
             # not a daemon: under TP the core process spawns the worker ranks itself
-            self._core = ctx.Process(target=_process_main, args=(cfg, child, device_index), daemon=False,
+            self._core = ctx.Process(target=_process_main, args=(cfg, child, device_index, os.getpid()), daemon=False,
                                      name="engine-core")
             self.engine = None
         else:

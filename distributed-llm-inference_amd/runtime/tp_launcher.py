@@ -47,7 +47,31 @@ def _join_group(cfg: EngineConfig, rank: int, world: int, port: int, base_index:
     return ctx, device
 
 
-def _worker_main(cfg: EngineConfig, rank: int, world: int, port: int, base_index: int):
+def _die_with_parent(parent_pid: int) -> None:
+    """A worker must not outlive its driver: blocked in a collective it would hold its GPU (and the KV cache)
+    forever.  PR_SET_PDEATHSIG delivers SIGKILL when the parent exits; a watchdog thread covers the window
+    before the prctl call and kernels that re-parent differently."""
+    import ctypes
+    import signal
+    import threading
+    import time
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)        # PR_SET_PDEATHSIG = 1
+    except OSError:
+        pass
+
+    def watch():
+        while True:
+            if os.getppid() != parent_pid:
+                os._exit(3)
+            time.sleep(1.0)
+
+    threading.Thread(target=watch, daemon=True, name="parent-watchdog").start()
+
+
+def _worker_main(cfg: EngineConfig, rank: int, world: int, port: int, base_index: int, parent_pid: int = 0):
+    if parent_pid:
+        _die_with_parent(parent_pid)
     from ..engine.engine import LLMEngine
     ctx, device = _join_group(cfg, rank, world, port, base_index)
     engine = LLMEngine(cfg, ctx, device)
@@ -72,7 +96,7 @@ def maybe_launch_tp(cfg: EngineConfig, base_index: int = 0) -> Optional[Parallel
     port = _free_port()
     spawn = mp.get_context("spawn")
     for rank in range(1, tp):
-        p = spawn.Process(target=_worker_main, args=(cfg, rank, tp, port, base_index), daemon=True, name=f"tp-worker-{rank}")
+        p = spawn.Process(target=_worker_main, args=(cfg, rank, tp, port, base_index, os.getpid()), daemon=True, name=f"tp-worker-{rank}")
         p.start()
         _children.append(p)
     ctx, _device = _join_group(cfg, 0, tp, port, base_index)

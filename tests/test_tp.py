@@ -47,3 +47,51 @@ def test_tp_pipelined_stepping_matches_single_rank():
     want = run("tiny-llama", 1, 1, prompts())
     got = run("tiny-llama", 2, 1, prompts(), pipelined=True)
     assert got == want
+
+
+def test_tp_workers_die_with_the_driver():
+    """A killed driver must not leave workers behind holding their device (failure handling)."""
+    import signal
+    import time
+    code = r'''
+import sys, os, time
+sys.path.insert(0, %r)
+from dli_amd.config import CacheConfig, EngineConfig, ParallelConfig, SchedulerConfig, get_model_config
+from dli_amd.engine.engine import LLMEngine
+from dli_amd.runtime import tp_launcher
+cfg = EngineConfig(model=get_model_config("tiny-llama"), cache=CacheConfig(num_blocks=64),
+                   sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=64, max_model_len=256),
+                   parallel=ParallelConfig(tp=2), device="cpu", use_hip_graphs=False)
+ctx = tp_launcher.maybe_launch_tp(cfg)
+eng = LLMEngine(cfg, ctx)
+print("CHILD", tp_launcher._children[0].pid, flush=True)
+time.sleep(120)
+''' % os.path.dirname(HERE)
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True,
+                         env=dict(os.environ, OMP_NUM_THREADS="2"))
+    try:
+        child = None
+        for line in p.stdout:
+            if line.startswith("CHILD "):
+                child = int(line.split()[1])
+                break
+        assert child is not None
+        time.sleep(0.5)
+        p.send_signal(signal.SIGKILL)
+        p.wait()
+        deadline = time.time() + 10
+        alive = True
+        while alive and time.time() < deadline:
+            try:
+                os.kill(child, 0)
+                with open(f"/proc/{child}/stat") as fh:        # a zombie awaiting reaping counts as gone
+                    alive = fh.read().split(")")[-1].split()[0] != "Z"
+            except (ProcessLookupError, FileNotFoundError):
+                alive = False
+            time.sleep(0.2)
+        if alive:
+            os.kill(child, signal.SIGKILL)
+        assert not alive, "TP worker outlived its driver"
+    finally:
+        if p.poll() is None:
+            p.kill()
