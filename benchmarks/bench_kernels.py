@@ -149,7 +149,7 @@ def bench_sampler(quick):
 
 def bench_moe(quick):
     H, I, E = 4096, 14336, 8
-    for T, El in ([(256, 8)] if quick else [(256, 8), (256, 1), (4096, 8), (4096, 1)]):
+    for T, El in ([(256, 8)] if quick else [(64, 8), (256, 8), (256, 1), (512, 8), (1024, 8), (4096, 8), (4096, 1)]):
         x = torch.randn(T, H, device=DEV).bfloat16()
         logits = torch.randn(T, E, device=DEV).bfloat16()
         w13 = (torch.randn(El, 2 * I, H, device=DEV) * 0.02).bfloat16()
