@@ -282,12 +282,18 @@ async def start_router(router: Router, host: str = "127.0.0.1", port: int = 0):
 
 
 def spawn_replicas(n: int, base_port: int, server_args: list[str], gpus: bool = True) -> list[subprocess.Popen]:
-    """One ``api_server`` process per GPU (``HIP_VISIBLE_DEVICES=i``), ports ``base_port + i``."""
+    """One ``api_server`` process per GPU (``HIP_VISIBLE_DEVICES=i``), ports ``base_port + i``.  With more
+    replicas than GPUs they wrap around (single-GPU rehearsal of the DP path: give each replica an explicit
+    ``--num-kv-blocks`` so that they do not all size their cache from the same free memory)."""
     procs = []
+    n_gpu = 1
+    if gpus:
+        import torch
+        n_gpu = max(torch.cuda.device_count(), 1)            # counting devices does not initialise the GPU
     for i in range(n):
         env = dict(os.environ)
         if gpus:
-            env["HIP_VISIBLE_DEVICES"] = str(i)
+            env["HIP_VISIBLE_DEVICES"] = str(i % n_gpu)
         cmd = [sys.executable, "-m", "dli_amd.server.api_server", "--host", "127.0.0.1", "--port", str(base_port + i)] + server_args
         procs.append(subprocess.Popen(cmd, env=env))
     return procs
