@@ -12,7 +12,8 @@
 // of the P·V MFMA, because the V page stores its 32 tokens in that register order
 // (ops/kv_layout.py).  K and V fragments are 16-byte loads straight from the page to VGPRs: every
 // wave-level load is one contiguous 1 KiB, each byte of the cache is read once per consumer wave,
-// so decode needs no LDS staging (memory-bound GEMV-like regime).
+// so decode needs no LDS staging (memory-bound GEMV-like regime: every wave walks different pages).
+// Prefill tiles share their pages between four waves and stage them through LDS (see below).
 //
 // qcol meaning:  decode  → query head inside the GQA group (G <= 16, padded columns are zero)
 //                prefill → query token inside a 16-token tile, one (head, tile) "column group" per
@@ -102,33 +103,40 @@ __device__ __forceinline__ float group_sum(float v) {
 
 // One 32-token page against one query-column set: Sᵀ → online softmax → Pᵀ fragment.
 // `limit`: tokens with index > limit are masked (limit = L-1 for decode, query position for prefill).
+// The scale is applied inside the exponent (one fma per element: exp2(s·scale − m)); the running maximum m is
+// kept in scaled units.
 template <bool MASK>
 __device__ __forceinline__ bf16x8 softmax_step(f32x4 (&s)[2], int tok0, int limit, float scale_log2, float& m,
                                                float& lsum, float& alpha) {
-  float mx = m;
+  float raw = NEG_BIG;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = s[rt][r] * scale_log2;
+      float v = s[rt][r];
       if (MASK) v = (tok0 + rt * 16 + r <= limit) ? v : NEG_BIG;
       s[rt][r] = v;
-      mx = fmaxf(mx, v);
+      raw = fmaxf(raw, v);
     }
-  mx = group_max(mx);
+  const float mx = group_max(fmaxf(m, raw * scale_log2));
   alpha = fast_exp2(m - mx);
   m = mx;
-  float ps = 0.f;
   bf16x8 pb;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 sc = {scale_log2, scale_log2, scale_log2, scale_log2}, nm = {-mx, -mx, -mx, -mx};
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < 2; ++rt) {
+    const f32x4 e = __builtin_elementwise_fma(s[rt], sc, nm);            // v_pk_fma_f32: two elements per instruction
+    f32x4 p;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float p = fast_exp2(s[rt][r] - mx);
-      if (MASK) p = (tok0 + rt * 16 + r <= limit) ? p : 0.f;
-      ps += p;
-      pb[rt * 4 + r] = (short)f2bf(p);
+      p[r] = fast_exp2(e[r]);
+      if (MASK) p[r] = (tok0 + rt * 16 + r <= limit) ? p[r] : 0.f;
+      pb[rt * 4 + r] = (short)f2bf(p[r]);
     }
+    acc += p;                                                            // v_pk_add_f32
+  }
+  const float ps = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   lsum = lsum * alpha + ps;
   return pb;
 }
@@ -259,23 +267,41 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
 // Prefill: grid (num_tiles, Hkv), 4 waves.  A tile is TQ = 16·(8/G) consecutive query tokens of one
 // sequence; its 8 column groups (head, 16-token sub-tile) are spread two per wave.  All K/V — paged
 // prefix and the chunk itself — come from the cache (rope_and_cache has already written the chunk).
+//
+// Unlike decode, all four waves of a tile walk the SAME pages, so the K and V pages are staged through
+// LDS: the block copies each 32-token page (K + V, 16 KB bf16 / 8 KB fp8) once, 16 bytes per lane,
+// into one of two LDS buffers while the MFMAs of the previous page run (global → registers before the
+// math, registers → LDS after it, one barrier per page), and every wave reads its fragments with
+// ds_read_b128.  That cuts the vector-memory traffic of the tile 4× (it was the limiter: 64 KB through
+// the texture path per page against 512 MFMA cycles).  The page keeps its global layout in LDS except
+// that the four 16-byte slots of every 64-byte row are permuted by the row (slot ^ h[(row >> 2) & 3],
+// h = {0,2,3,1}): the 16 lanes the hardware serves together for a ds_read_b128 — {0–3, 12–15, 20–27}
+// etc. — then touch 16 different slots of the 256-byte bank row instead of 8.
 // ==================================================================================================
+__device__ __forceinline__ int slot_swizzle(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
 template <bool KV8>
-__global__ __launch_bounds__(256) void paged_prefill_kernel(
+__global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens,
     const int* __restrict__ query_start_loc, const int* __restrict__ tile_seq, const int* __restrict__ tile_q0,
     uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, float scale_log2, float v_scale) {
+  constexpr int ESZ = KV8 ? 1 : 2;
+  constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;            // one K (or V) page of one kv head
+  constexpr int NCH = PAGE_BYTES / (16 * 256);            // 16-byte chunks per thread and operand: 2 (bf16) / 1 (fp8)
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * PAGE_BYTES];   // [buffer][K | V]
+
   const int kvh = blockIdx.y;
   const int G = Hq / Hkv;                      // 1, 2, 4 or 8 (checked on the host)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = lane & 15, g = lane >> 4;
-  const int seq = tile_seq[blockIdx.x], q0 = tile_q0[blockIdx.x];
+  // work list in reverse: within a sequence the later tiles see more context (causal), so the long ones start first
+  const int tile_id = gridDim.x - 1 - blockIdx.x;
+  const int seq = tile_seq[tile_id], q0 = tile_q0[tile_id];
   const int qs = query_start_loc[seq];
   const int n_new = query_start_loc[seq + 1] - qs;
   const int L = seq_lens[seq];
   const int ctx = L - n_new;
-  constexpr int ESZ = KV8 ? 1 : 2;
 
   int head[2], qtok[2], qpos[2];
   bool valid[2];
@@ -293,8 +319,11 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
       last_pos = max(last_pos, ctx + min(t0 + 15, n_new - 1));
     }
   }
-  if (last_pos < 0) return;                    // both sub-tiles are past the end of the chunk
-  const int nblk = (last_pos >> 5) + 1;
+  // Every wave takes part in staging all pages of the tile; the math stops at the wave's own causal horizon
+  // (waves whose sub-tiles lie past the end of the chunk do no math at all).
+  const int my_nblk = last_pos < 0 ? 0 : (last_pos >> 5) + 1;
+  const int tile_tokens = 16 * (8 / G);
+  const int nblk = ((ctx + min(q0 + tile_tokens, n_new) - 1) >> 5) + 1;
 
   bf16x8 qf[2][4];
 #pragma unroll
@@ -315,35 +344,97 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
   const char* kc = reinterpret_cast<const char*>(k_cache);
   const char* vc = reinterpret_cast<const char*>(v_cache);
 
-  for (int b = 0; b < nblk; ++b) {
-    const int64_t page = ((int64_t)bt[b] * Hkv + kvh) * (PAGE_ELEMS * ESZ);
-    bf16x8 kf[2][4];
-    KLoader<KV8>::load(kc + page, col, g, kf);
-    const bool need_mask = b * 32 + 31 > first_tok;   // some query of this wave sits before the page end
-    bf16x8 pb[2];
-    float alpha[2];
+  // ---- staging: LDS-DMA (global_load_lds, 16 bytes per lane, no VGPRs).  One wave instruction fills 1 KB of LDS in
+  // lane order, so the slot permutation is applied on the SOURCE side: LDS chunk ci = (row, physical slot) receives
+  // global chunk (row, slot ^ h(row)).  Thread owns LDS chunks ci = tid + 256 i of the K page and of the V page.
+  int src_k[NCH], src_v[NCH];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      f32x4 s[2];
+  for (int i = 0; i < NCH; ++i) {
+    const int ci = tid + 256 * i, row = ci >> 2, slot = ci & 3;
+    src_k[i] = (row * 4 + (slot ^ slot_swizzle(row))) * 16;                // 64-byte rows in both dtypes
+    src_v[i] = KV8 ? ci * 16 : src_k[i];                                   // fp8 V: 32-byte rows, 8-byte reads, linear
+  }
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+#define DLI_STAGE(b_, buf_)                                                                                        \
+  {                                                                                                                \
+    const int64_t page_ = ((int64_t)bt[b_] * Hkv + kvh) * PAGE_BYTES;                                             \
+    _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                                              \
+      char* dst_ = smem + (buf_) * 2 * PAGE_BYTES + (wave + 4 * i) * 1024;       /* wave-uniform; + lane·16 by hardware */ \
+      __builtin_amdgcn_global_load_lds((gptr_t)(kc + page_ + src_k[i]), (lptr_t)dst_, 16, 0, 0);                   \
+      __builtin_amdgcn_global_load_lds((gptr_t)(vc + page_ + src_v[i]), (lptr_t)(dst_ + PAGE_BYTES), 16, 0, 0);    \
+    }                                                                                                              \
+  }
+  const int lane_off = col * 64 + ((g ^ slot_swizzle(col)) << 4);           // this lane's 16 bytes of a 16-row group
+
+  DLI_STAGE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int b = 0; b < nblk; ++b) {
+    const bool more = b + 1 < nblk;
+    // next page → the buffer read during page b-1 (every wave is past that barrier); in flight under this page's math
+    if (more) DLI_STAGE(b + 1, (b + 1) & 1);
+    if (b < my_nblk) {
+      const char* kb = smem + (b & 1) * 2 * PAGE_BYTES;
+      const char* vb = kb + PAGE_BYTES;
+      const bool need_mask = b * 32 + 31 > first_tok;   // some query of this wave sits before the page end
+      f32x4 s[2][2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        s[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 kf[4];
+        if constexpr (!KV8) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[rt] = mfma16(kf[rt][c], qf[i][c], s[rt]);
+          for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(kb + (c * 32 + rt * 16) * 64 + lane_off);
+        } else {
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(kb + (c2 * 32 + rt * 16) * 64 + lane_off);
+            fp8x4_to_bf16(raw.x, kf[2 * c2], 0);
+            fp8x4_to_bf16(raw.y, kf[2 * c2], 4);
+            fp8x4_to_bf16(raw.z, kf[2 * c2 + 1], 0);
+            fp8x4_to_bf16(raw.w, kf[2 * c2 + 1], 4);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          s[i][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s[i][rt] = mfma16(kf[c], qf[i][c], s[i][rt]);
+        }
       }
+      bf16x8 pb[2];
+      float alpha[2];
       const int tok0 = b * 32 + 4 * g;
-      if (need_mask) pb[i] = softmax_step<true>(s, tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
-      else pb[i] = softmax_step<false>(s, tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
-    }
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const bf16x8 vf = load_v<KV8>(vc + page, n, col, g);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        o[i][n] *= alpha[i];
-        o[i][n] = mfma16(vf, pb[i], o[i][n]);
+        if (need_mask) pb[i] = softmax_step<true>(s[i], tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
+        else pb[i] = softmax_step<false>(s[i], tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
+      }
+      // the running maximum settles after the first pages: skip the 64 accumulator multiplies when no lane moved
+      // (a real branch — the empty asm keeps the compiler from turning it into 64 selects)
+      if (__any(alpha[0] != 1.f || alpha[1] != 1.f)) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 8; ++n) o[i][n] *= alpha[i];
+      }
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        bf16x8 vf;
+        if constexpr (!KV8) {
+          vf = *reinterpret_cast<const bf16x8*>(vb + (16 * n) * 64 + lane_off);
+        } else {
+          const uint2 raw = *reinterpret_cast<const uint2*>(vb + (16 * n + col) * 32 + 8 * g);
+          fp8x4_to_bf16(raw.x, vf, 0);
+          fp8x4_to_bf16(raw.y, vf, 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) o[i][n] = mfma16(vf, pb[i], o[i][n]);
       }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the next page has landed in LDS
+    __syncthreads();
   }
 
 #pragma unroll
@@ -360,6 +451,7 @@ __global__ __launch_bounds__(256) void paged_prefill_kernel(
       *reinterpret_cast<bf16x4*>(op + 16 * n) = w;
     }
   }
+#undef DLI_STAGE
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
