@@ -198,12 +198,219 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const T* __restrict__ logit
   if (threadIdx.x == 0) out[b] = a.i;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 fast path (the serving path: logits come out of the LM-head GEMM in bf16, V ≤ 131072, V % 8 == 0).
+// The whole row lives in registers — thread t holds 16-byte chunks t, t+1024, … (8 logits each, packed) — so
+// every later pass (max, mass, radix, draw) is register work and the row is read from memory exactly once.
+// A bf16 logit has only 16 key bits, so the radix descent takes TWO 8-bit passes (not four), and a thread adds
+// runs of equal bins to the LDS histogram with one atomic (softmax-shaped rows put most of a thread's elements
+// in the same two or three bins; per-element atomics on them serialise the whole workgroup).
+// The Philox counter of element i is i/4 exactly as in the generic kernel: both paths draw the same token.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t okey16(uint32_t h) { return (h & 0x8000u) ? (~h & 0xFFFFu) : (h | 0x8000u); }
+__device__ __forceinline__ uint32_t half_of(const uint4& c, int e) {   // e-th bf16 (0..7) of a chunk, compile-time e
+  const uint32_t w = e < 2 ? c.x : e < 4 ? c.y : e < 6 ? c.z : c.w;
+  return (e & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+// Every pass re-derives keys and weights from the packed row.  Without this fence the compiler keeps the 128 unpacked
+// keys of a thread alive from one pass to the next (CSE) and spills; the empty asm makes the registers opaque.
+template <int NCH>
+__device__ __forceinline__ void opaque(uint4 (&regs)[NCH]) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) asm volatile("" : "+v"(regs[c].x), "+v"(regs[c].y), "+v"(regs[c].z), "+v"(regs[c].w));
+}
+
+// descending walk over 256 bins by one wave: first bin where the running total reaches `remaining`
+__device__ __forceinline__ void pick_bin(const float* hist, float remaining, uint32_t* s_pick, float* s_rem) {
+  const int lane = threadIdx.x;                       // called by threads 0..63
+  float h[4], local = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { h[j] = hist[255 - 4 * lane - j]; local += h[j]; }
+  float incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float up = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += up;
+  }
+  const uint64_t hit = __ballot(incl >= remaining);
+  const int first = hit ? __ffsll((long long)hit) - 1 : 63;
+  if (lane == first) {
+    float acc = incl - local;
+    int j = 0;
+    for (; j < 3; ++j) {
+      if (acc + h[j] >= remaining) break;
+      acc += h[j];
+    }
+    if (!hit) { j = 3; acc = incl - h[3]; }           // total < remaining (rounding): lowest bin, like the serial walk
+    *s_pick = (uint32_t)(255 - 4 * lane - j);
+    *s_rem = remaining - acc;
+  }
+}
+
+template <int NCH, bool MASS>
+__device__ __forceinline__ uint32_t radix_cut16(uint4 (&regs)[NCH], float inv_t_log2, float zmax, float target, uint32_t floor_key,
+                                float* hist, uint32_t* s_pick, float* s_rem) {
+  uint32_t prefix = 0;
+  float remaining = target;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shift = pass == 0 ? 8 : 0;
+    for (int i = threadIdx.x; i < 256; i += SNT) hist[i] = 0.f;
+    __syncthreads();
+    opaque(regs);
+    int cur_bin = -1;
+    float cur = 0.f;
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint32_t h = half_of(regs[c], e);
+        const uint32_t k = okey16(h);
+        const bool take = k >= floor_key && (pass == 0 || (k >> 8) == (prefix >> 8));
+        if (take) {
+          const float w = MASS ? fast_exp2(bf2f((uint16_t)h) * inv_t_log2 - zmax) : 1.f;
+          const int bin = (int)((k >> shift) & 255u);
+          if (bin == cur_bin) {
+            cur += w;
+          } else {
+            if (cur_bin >= 0) atomicAdd(&hist[cur_bin], cur);
+            cur_bin = bin;
+            cur = w;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one chunk at a time: keeps the 64 row registers the only long-lived ones
+    }
+    if (cur_bin >= 0) atomicAdd(&hist[cur_bin], cur);
+    __syncthreads();
+    if (threadIdx.x < 64) pick_bin(hist, remaining, s_pick, s_rem);
+    __syncthreads();
+    prefix |= (*s_pick) << shift;
+    remaining = *s_rem;
+    __syncthreads();
+  }
+  return prefix;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(SNT) void sample_bf16_kernel(const uint16_t* __restrict__ logits, int64_t row_stride, int V,
+                                                          const float* __restrict__ temperature, const float* __restrict__ top_p,
+                                                          const int* __restrict__ top_k, const int64_t* __restrict__ seeds,
+                                                          const int64_t* __restrict__ steps, const float* __restrict__ noise,
+                                                          int64_t* __restrict__ out) {
+  __shared__ float sv[SNT / 64];
+  __shared__ int si[SNT / 64];
+  __shared__ float hist[256];
+  __shared__ uint32_t s_pick;
+  __shared__ float s_rem;
+
+  const int b = blockIdx.x;
+  const uint4* row = reinterpret_cast<const uint4*>(logits + (int64_t)b * row_stride);
+  const int nchunks = V >> 3;
+  uint4 regs[NCH];
+#pragma clang loop unroll(full)
+  for (int c = 0; c < NCH; ++c) {
+    const int idx = c * SNT + threadIdx.x;
+    regs[c] = idx < nchunks ? row[idx] : make_uint4(0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u, 0xFF80FF80u);   // -inf padding
+  }
+  const float temp = temperature[b];
+
+  if (temp <= 0.f) {
+    ArgMax a{-3.0e38f, 0x7fffffff};
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        a = amax(a, ArgMax{bf2f((uint16_t)half_of(regs[c], e)), (c * SNT + (int)threadIdx.x) * 8 + e});
+    a = block_argmax(a, sv, si);
+    if (threadIdx.x == 0) out[b] = a.i;
+    return;
+  }
+
+  const float inv_t_log2 = 1.4426950408889634f / temp;    // z = x / T in log2 units
+  const float p = top_p[b];
+  int k = top_k[b];
+  if (k <= 0 || k > V) k = V;
+  uint32_t floor_key = 0;                                  // 16-bit key of the raw bf16 logit (x → x/T is monotone)
+
+  if (k < V || p < 1.f) {
+    float zmax = -3.0e38f;
+    opaque(regs);
+#pragma clang loop unroll(full)
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) zmax = fmaxf(zmax, bf2f((uint16_t)half_of(regs[c], e)));
+    zmax = block_max(zmax, sv) * inv_t_log2;
+    if (k < V) floor_key = radix_cut16<NCH, false>(regs, inv_t_log2, zmax, (float)k, 0u, hist, &s_pick, &s_rem);
+    if (p < 1.f) {
+      float tot = 0.f;                                     // mass of what survived top-k
+      opaque(regs);
+#pragma clang loop unroll(full)
+      for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t h = half_of(regs[c], e);
+          if (okey16(h) >= floor_key) tot += fast_exp2(bf2f((uint16_t)h) * inv_t_log2 - zmax);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      tot = wave_sum(tot);
+      if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = tot;
+      __syncthreads();
+      tot = 0.f;
+      for (int w = 0; w < SNT / 64; ++w) tot += sv[w];
+      __syncthreads();
+      floor_key = radix_cut16<NCH, true>(regs, inv_t_log2, zmax, p * tot, floor_key, hist, &s_pick, &s_rem);
+    }
+  }
+
+  const uint64_t seed = (uint64_t)seeds[b];
+  const uint64_t step = (uint64_t)steps[b];
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  ArgMax a{-3.0e38f, 0x7fffffff};
+  const float ln2 = 0.6931471805599453f;
+  opaque(regs);
+#pragma clang loop unroll(full)
+  for (int c = 0; c < NCH; ++c) {
+    const int chunk = c * SNT + (int)threadIdx.x;
+    if (chunk < nchunks) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int i4 = chunk * 2 + half;
+        uint4 r = make_uint4(0, 0, 0, 0);
+        if (noise == nullptr) r = philox4x32_10(make_uint4((uint32_t)i4, (uint32_t)step, (uint32_t)(step >> 32), 0x5A17u), key);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t h = half_of(regs[c], half * 4 + e);
+          if (okey16(h) >= floor_key) {
+            const int i = i4 * 4 + e;
+            const float u = noise != nullptr ? noise[(int64_t)b * V + i] : u01(rr[e]);
+            a = amax(a, ArgMax{bf2f((uint16_t)h) * inv_t_log2 * ln2 + gumbel(u), i});
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  a = block_argmax(a, sv, si);
+  if (threadIdx.x == 0) out[b] = a.i;
+}
+
 void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int B, int V, const float* temperature,
                    const float* top_p, const int* top_k, const int64_t* seeds, const int64_t* steps, const float* noise,
                    int64_t* out, hipStream_t stream) {
   if (B == 0) return;
+  const bool rows16 = V % 8 == 0 && row_stride % 8 == 0 && reinterpret_cast<uintptr_t>(logits) % 16 == 0;
   if (logits_fp32)
     hipLaunchKernelGGL(sample_kernel<float>, dim3(B), dim3(SNT), 0, stream, (const float*)logits, row_stride, V,
+                       temperature, top_p, top_k, seeds, steps, noise, out);
+  else if (rows16 && V <= 4 * SNT * 8)
+    hipLaunchKernelGGL(sample_bf16_kernel<4>, dim3(B), dim3(SNT), 0, stream, (const uint16_t*)logits, row_stride, V,
+                       temperature, top_p, top_k, seeds, steps, noise, out);
+  else if (rows16 && V <= 16 * SNT * 8)
+    hipLaunchKernelGGL(sample_bf16_kernel<16>, dim3(B), dim3(SNT), 0, stream, (const uint16_t*)logits, row_stride, V,
                        temperature, top_p, top_k, seeds, steps, noise, out);
   else
     hipLaunchKernelGGL(sample_kernel<uint16_t>, dim3(B), dim3(SNT), 0, stream, (const uint16_t*)logits, row_stride, V,
