@@ -114,6 +114,10 @@ class LLMEngine:
             if self.ctx.tp_size > 1 and self.metrics.steps % 128 == 0:
                 from ..runtime.tp_launcher import check_children
                 check_children()                             # a dead TP worker would hang the next collective
+                ar = getattr(self.ctx, "custom_ar", None)
+                if ar is not None and ar.enabled and ar.error():
+                    # a peer never raised its flag: the kernel gave up after its bounded spin, sums are not trustworthy
+                    raise RuntimeError("custom all-reduce timed out waiting for a peer GPU; aborting the engine")
             with trace_range(f"launch[T={batch.total_tokens},B={len(batch.requests)}]"):
                 handle = self.runner.launch(batch, self.bm)
                 self.scheduler.advance(batch, self.cfg.sched.max_model_len)
