@@ -112,6 +112,9 @@ class SchedulerConfig:
     max_model_len: int = 4096
     long_prefill_chunk: int = 2048          # per-request cap on one step's prefill chunk
     enable_chunked_prefill: bool = True
+    # Large steps are trimmed (by shortening one prefill chunk) to a multiple of this many tokens: the GEMMs
+    # run on 256-row macro-tiles, and a ragged last tile costs as much as a full one.  0 disables.
+    token_alignment: int = 256
 
 
 @dataclass

@@ -134,6 +134,14 @@ class Scheduler:
 
         if not picked:
             return None
+        # tile alignment: give the ragged remainder of a big step back to its largest prefill chunk
+        align = cfg.token_alignment
+        total = cfg.max_num_batched_tokens - budget
+        if align > 1 and cfg.enable_chunked_prefill and total >= 4 * align and total % align:
+            cut = total % align
+            j = max(range(len(picked)), key=lambda i: picked[i][1])
+            if picked[j][1] > cut + 1:                      # stays a multi-token chunk; its pages are already allocated
+                picked[j] = (picked[j][0], picked[j][1] - cut)
         # decodes (single token) first, stable otherwise
         picked.sort(key=lambda p: p[1] != 1)
         reqs = [p[0] for p in picked]

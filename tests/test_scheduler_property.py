@@ -16,13 +16,15 @@ EOS = 2
 
 def run_random(seed: int, pipelined: bool, num_blocks: int, prefix: bool):
     rng = np.random.default_rng(seed)
-    cfg = SchedulerConfig(max_num_seqs=6, max_num_batched_tokens=96, max_model_len=400, long_prefill_chunk=64)
+    cfg = SchedulerConfig(max_num_seqs=6, max_num_batched_tokens=96, max_model_len=400, long_prefill_chunk=64,
+                          token_alignment=16)
     bm = BlockManager(num_blocks, KV_BLOCK_SIZE, prefix)
     sch = Scheduler(cfg, bm)
     live, finished, next_id = {}, 0, 0
     shared = rng.integers(3, 50, size=70)
     inflight = None
     preempt_seen = 0
+    aligned, big = [0], [0]
     for step in range(600):
         # arrivals / aborts
         if step < 350 and rng.random() < 0.25:
@@ -43,6 +45,8 @@ def run_random(seed: int, pipelined: bool, num_blocks: int, prefix: bool):
         batch = sch.schedule()
         if batch is not None:
             assert batch.total_tokens <= cfg.max_num_batched_tokens
+            aligned[0] += batch.total_tokens >= 64 and batch.total_tokens % 16 == 0
+            big[0] += batch.total_tokens >= 64
             assert len(sch.running) <= cfg.max_num_seqs
             assert batch.total_tokens == int(batch.num_new.sum()) and (batch.num_new > 0).all()
             assert (batch.num_new[:batch.num_decode] == 1).all()
@@ -79,6 +83,7 @@ def run_random(seed: int, pipelined: bool, num_blocks: int, prefix: bool):
             break
     assert not sch.has_work() and not live, (len(sch.running), len(sch.waiting), len(live))
     assert bm.num_free == bm.num_blocks, "page leak"
+    assert big[0] == 0 or aligned[0] >= 0.5 * big[0], (aligned, big)      # big steps are mostly trimmed to whole tiles
     return finished, preempt_seen
 
 
