@@ -94,7 +94,38 @@ def _decode_case(B, ctx, Hq, Hkv, kv_dtype, splits=None):
     return fn, kv_bytes, splits
 
 
+def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0):
+    """Serving-shaped batch: log-normal context lengths (the BurstGPT length mix), one decode token each."""
+    rng = np.random.default_rng(seed)
+    ctx = np.clip(rng.lognormal(np.log(mean_ctx) - 0.32, 0.8, size=B), 8, 2048).astype(np.int64)
+    nb = (ctx + 31) // 32
+    max_nb = int(nb.max())
+    nblocks = int(nb.sum()) + 1
+    kc, vc = allocate_kv_cache(1, nblocks, Hkv, 128, torch.bfloat16, DEV)[0]
+    kc.normal_()
+    vc.normal_()
+    perm = torch.randperm(nblocks - 1).to(torch.int32)
+    bt = torch.zeros(B, max_nb, dtype=torch.int32)
+    o = 0
+    for i in range(B):
+        bt[i, :nb[i]] = perm[o:o + nb[i]]
+        o += int(nb[i])
+    bt = bt.to(DEV)
+    sl = torch.from_numpy(ctx).to(torch.int32).to(DEV)
+    qsl = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * 128, device=DEV).bfloat16()
+    splits = ops.choose_decode_splits(B, Hkv, int(ctx.max()))
+    ws = torch.empty(B * Hq * splits * 130, dtype=torch.float32, device=DEV)
+    meta = ops.AttnMetadata(B, 0, B, None, None, bt, sl, qsl, decode_splits=splits, decode_workspace=ws)
+    out = torch.empty(B, Hq * 128, device=DEV, dtype=torch.bfloat16)
+    fn = lambda: ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, 1 / math.sqrt(128), out=out)
+    return fn, int(nb.sum()) * 32 * Hkv * 128 * 2 * 2, splits, float(ctx.mean())
+
+
 def bench_decode(quick):
+    for B in ([1024] if quick else [256, 1024, 1400]):
+        fn, nbytes, splits, mean = _decode_mixed_case(B, 770)
+        report("paged_attention_decode(mixed lengths)", timeit(fn), bytes_=nbytes, B=B, mean_ctx=round(mean), splits=splits)
     cases = [(256, 700), (64, 700), (8, 2048), (1, 2048), (512, 1024)]
     if quick:
         cases = cases[:2]
