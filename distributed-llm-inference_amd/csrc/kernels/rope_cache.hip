@@ -1,6 +1,6 @@
 // K2: NeoX rotate-half RoPE on q and k fused with the paged-KV write.
 //
-// One 256-thread workgroup per token.  Work items are 8-element (16-byte) chunks: a q/k item owns
+// One 256-thread workgroup per 4 consecutive tokens.  Work items are 8-element (16-byte) chunks: a q/k item owns
 // the pair (x[d0:d0+8], x[d0+64:d0+72]) of one head, so both halves of the rotation are produced by
 // the same thread; cos/sin come from a host-built fp32 table (no device trig).  Rotated k goes back
 // into the qkv buffer (the prefill kernel reads everything from the cache, but the in-place result
@@ -17,79 +17,122 @@ constexpr int D = 128;
 
 __device__ __forceinline__ int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
 
+constexpr int TB = 4;   // tokens per workgroup
+
 template <bool KV8>
 __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv, int64_t row_stride,
                                                          const int* __restrict__ positions,
                                                          const float* __restrict__ cos_sin,  // [max_pos, D] or null
                                                          const int* __restrict__ slot_mapping,
                                                          void* __restrict__ k_cache_, void* __restrict__ v_cache_,
-                                                         int Hq, int Hkv, float k_inv_scale, float v_inv_scale) {
-  const int64_t t = blockIdx.x;
-  uint16_t* row = qkv + t * row_stride;
-  const int slot = slot_mapping[t];
-  const int pos = positions[t];
-  const int blk = slot >> 5, tok = slot & 31;
+                                                         int T, int Hq, int Hkv, float k_inv_scale, float v_inv_scale) {
+  const int t0 = blockIdx.x * TB;
+  const int nt = min(TB, T - t0);
   const int n_rot = (Hq + Hkv) * 8;
-  const int n_items = n_rot + Hkv * 16;
 
-  for (int it = threadIdx.x; it < n_items; it += blockDim.x) {
-    if (it < n_rot) {
-      const int head = it >> 3, j = it & 7;
-      uint16_t* p = row + head * D + j * 8;
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-      bf16x8 b = *reinterpret_cast<const bf16x8*>(p + 64);
+  // ---- q/k: rotate in place, k also into its K page.  Items of the TB tokens are flattened so that every pass of the
+  // 256 threads is full ((Hq+Hkv)·8 = 320 items per token for Llama-3-8B).
+  for (int it = threadIdx.x; it < n_rot * nt; it += blockDim.x) {
+    const int ti = it / n_rot, r = it - ti * n_rot;
+    const int64_t t = t0 + ti;
+    uint16_t* row = qkv + t * row_stride;
+    const int slot = slot_mapping[t];
+    const int head = r >> 3, j = r & 7;
+    uint16_t* p = row + head * D + j * 8;
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+    bf16x8 b = *reinterpret_cast<const bf16x8*>(p + 64);
+    if (cos_sin != nullptr) {
       float fa[8], fb[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { fa[e] = bf2f((uint16_t)a[e]); fb[e] = bf2f((uint16_t)b[e]); }
-      if (cos_sin != nullptr) {
-        const float* cs = cos_sin + (int64_t)pos * D + j * 8;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64), s1 = *reinterpret_cast<const f32x4*>(cs + 68);
+      const float* cs = cos_sin + (int64_t)positions[t] * D + j * 8;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64), s1 = *reinterpret_cast<const f32x4*>(cs + 68);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float c = e < 4 ? c0[e] : c1[e - 4], sn = e < 4 ? s0[e] : s1[e - 4];
+        const float x1 = fa[e], x2 = fb[e];
+        a[e] = (short)f2bf(x1 * c - x2 * sn);
+        b[e] = (short)f2bf(x2 * c + x1 * sn);
+      }
+      *reinterpret_cast<bf16x8*>(p) = a;
+      *reinterpret_cast<bf16x8*>(p + 64) = b;
+    }
+    if (head >= Hq && slot >= 0) {             // k head → K page
+      const int h = head - Hq, blk = slot >> 5, tok = slot & 31;
+      const int64_t page = (int64_t)blk * Hkv + h;
+      if (!KV8) {
+        uint16_t* kc = reinterpret_cast<uint16_t*>(k_cache_) + page * (D * 32);
+        const int d0 = j * 8, d1 = 64 + j * 8;   // chunk c = d/32, offset d%32
+        *reinterpret_cast<bf16x8*>(kc + ((d0 >> 5) * 32 + tok) * 32 + (d0 & 31)) = a;
+        *reinterpret_cast<bf16x8*>(kc + ((d1 >> 5) * 32 + tok) * 32 + (d1 & 31)) = b;
+      } else {
+        uint8_t* kc = reinterpret_cast<uint8_t*>(k_cache_) + page * (D * 32);
+        uint64_t pa = 0, pb = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float c = e < 4 ? c0[e] : c1[e - 4], s = e < 4 ? s0[e] : s1[e - 4];
-          const float x1 = fa[e], x2 = fb[e];
-          fa[e] = x1 * c - x2 * s;
-          fb[e] = x2 * c + x1 * s;
+          pa |= (uint64_t)f_to_fp8(bf2f((uint16_t)a[e]) * k_inv_scale) << (8 * e);
+          pb |= (uint64_t)f_to_fp8(bf2f((uint16_t)b[e]) * k_inv_scale) << (8 * e);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = (short)f2bf(fa[e]); b[e] = (short)f2bf(fb[e]); }
-        *reinterpret_cast<bf16x8*>(p) = a;
-        *reinterpret_cast<bf16x8*>(p + 64) = b;
+        // chunk c = d/64: first half is chunk 0, second half chunk 1
+        *reinterpret_cast<uint64_t*>(kc + (0 * 32 + tok) * 64 + j * 8) = pa;
+        *reinterpret_cast<uint64_t*>(kc + (1 * 32 + tok) * 64 + j * 8) = pb;
       }
-      if (head >= Hq && slot >= 0) {             // k head → K page
-        const int h = head - Hq;
-        const int64_t page = (int64_t)blk * Hkv + h;
-        if (!KV8) {
-          uint16_t* kc = reinterpret_cast<uint16_t*>(k_cache_) + page * (D * 32);
-          const int d0 = j * 8, d1 = 64 + j * 8;   // chunk c = d/32, offset d%32
-          *reinterpret_cast<bf16x8*>(kc + ((d0 >> 5) * 32 + tok) * 32 + (d0 & 31)) = a;
-          *reinterpret_cast<bf16x8*>(kc + ((d1 >> 5) * 32 + tok) * 32 + (d1 & 31)) = b;
-        } else {
-          uint8_t* kc = reinterpret_cast<uint8_t*>(k_cache_) + page * (D * 32);
-          uint64_t pa = 0, pb = 0;
+    }
+  }
+
+  // ---- v → transposed V page.  Tokens 4k…4k+3 of a page occupy 4 ADJACENT slots of every d row (v_slot), so a
+  // prefill chunk — whose TB tokens sit in consecutive cache slots — is written with one 8-byte store per (d row,
+  // 4 tokens) instead of four 2-byte ones.  Decode tokens (one per sequence, unrelated slots) take the scalar path.
+  const int s_first = slot_mapping[t0];
+  bool grouped = nt == TB && s_first >= 0 && (s_first & 3) == 0;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pa |= (uint64_t)f_to_fp8(bf2f((uint16_t)a[e]) * k_inv_scale) << (8 * e);
-            pb |= (uint64_t)f_to_fp8(bf2f((uint16_t)b[e]) * k_inv_scale) << (8 * e);
-          }
-          // chunk c = d/64: first half is chunk 0, second half chunk 1
-          *reinterpret_cast<uint64_t*>(kc + (0 * 32 + tok) * 64 + j * 8) = pa;
-          *reinterpret_cast<uint64_t*>(kc + (1 * 32 + tok) * 64 + j * 8) = pb;
-        }
-      }
-    } else if (slot >= 0) {                      // v chunk → transposed V page
-      const int vi = it - n_rot;
+  for (int i = 1; i < TB; ++i) grouped = grouped && (i >= nt || slot_mapping[t0 + i] == s_first + i);
+  if (grouped) {
+    const int blk = s_first >> 5, sl = v_slot(s_first & 31);
+    for (int vi = threadIdx.x; vi < Hkv * 16; vi += blockDim.x) {
       const int h = vi >> 4, d0 = (vi & 15) * 8;
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(row + (Hq + Hkv + h) * D + d0);
+      bf16x8 x[TB];
+#pragma unroll
+      for (int i = 0; i < TB; ++i)
+        x[i] = *reinterpret_cast<const bf16x8*>(qkv + (int64_t)(t0 + i) * row_stride + (Hq + Hkv + h) * D + d0);
       const int64_t page = (int64_t)blk * Hkv + h;
-      const int s = v_slot(tok);
       if (!KV8) {
-        uint16_t* vc = reinterpret_cast<uint16_t*>(v_cache_) + page * (D * 32) + d0 * 32 + s;
+        uint16_t* vc = reinterpret_cast<uint16_t*>(v_cache_) + page * (D * 32) + d0 * 32 + sl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bf16x4 w;
+#pragma unroll
+          for (int i = 0; i < TB; ++i) w[i] = x[i][e];
+          *reinterpret_cast<bf16x4*>(vc + e * 32) = w;
+        }
+      } else {
+        uint8_t* vc = reinterpret_cast<uint8_t*>(v_cache_) + page * (D * 32) + d0 * 32 + sl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int i = 0; i < TB; ++i) w |= (uint32_t)f_to_fp8(bf2f((uint16_t)x[i][e]) * v_inv_scale) << (8 * i);
+          *reinterpret_cast<uint32_t*>(vc + e * 32) = w;
+        }
+      }
+    }
+  } else {
+    for (int it = threadIdx.x; it < Hkv * 16 * nt; it += blockDim.x) {
+      const int ti = it / (Hkv * 16), vi = it - ti * (Hkv * 16);
+      const int64_t t = t0 + ti;
+      const int slot = slot_mapping[t];
+      if (slot < 0) continue;
+      const int h = vi >> 4, d0 = (vi & 15) * 8;
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(qkv + t * row_stride + (Hq + Hkv + h) * D + d0);
+      const int64_t page = (int64_t)(slot >> 5) * Hkv + h;
+      const int sl = v_slot(slot & 31);
+      if (!KV8) {
+        uint16_t* vc = reinterpret_cast<uint16_t*>(v_cache_) + page * (D * 32) + d0 * 32 + sl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) vc[e * 32] = (uint16_t)a[e];
       } else {
-        uint8_t* vc = reinterpret_cast<uint8_t*>(v_cache_) + page * (D * 32) + d0 * 32 + s;
+        uint8_t* vc = reinterpret_cast<uint8_t*>(v_cache_) + page * (D * 32) + d0 * 32 + sl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) vc[e * 32] = f_to_fp8(bf2f((uint16_t)a[e]) * v_inv_scale);
       }
@@ -101,12 +144,13 @@ void launch_rope_and_cache(void* qkv, int64_t row_stride, const int* positions, 
                            const int* slot_mapping, void* k_cache, void* v_cache, int T, int Hq, int Hkv,
                            bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
   if (T == 0) return;
+  const dim3 grid((T + TB - 1) / TB);
   if (kv_fp8)
-    hipLaunchKernelGGL(rope_cache_kernel<true>, dim3(T), dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
-                       cos_sin, slot_mapping, k_cache, v_cache, Hq, Hkv, 1.f / k_scale, 1.f / v_scale);
+    hipLaunchKernelGGL(rope_cache_kernel<true>, grid, dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
+                       cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, 1.f / k_scale, 1.f / v_scale);
   else
-    hipLaunchKernelGGL(rope_cache_kernel<false>, dim3(T), dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
-                       cos_sin, slot_mapping, k_cache, v_cache, Hq, Hkv, 1.f, 1.f);
+    hipLaunchKernelGGL(rope_cache_kernel<false>, grid, dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
+                       cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, 1.f, 1.f);
 }
 
 // K9 helper: device-side page copy for copy-on-write (pairs = [n, 2] int32: src, dst page ids).

@@ -66,11 +66,20 @@ def _caches(nblocks, hkv, dtype=torch.bfloat16, layers=1):
 
 @pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1), (4, 4)])
 @pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float8_e4m3fn])
-def test_rope_and_cache(Hq, Hkv, kv_dtype):
+@pytest.mark.parametrize("layout", ["scattered", "chunk", "mixed"])
+def test_rope_and_cache(Hq, Hkv, kv_dtype, layout):
+    """scattered: decode-like (unrelated slots, scalar V stores); chunk: a prefill chunk in consecutive slots starting
+    mid-group (the 4-token grouped V stores and the unaligned edges); mixed: decode rows followed by a chunk."""
     T, nblocks = 75, 16
     qkv = _bf(T, (Hq + 2 * Hkv) * 128, seed=9)
     pos = torch.randint(0, 4000, (T,), dtype=torch.int32, device=DEV)
-    slots = torch.randperm(nblocks * 32, device=DEV)[:T].to(torch.int32)
+    if layout == "scattered":
+        slots = torch.randperm(nblocks * 32, device=DEV)[:T].to(torch.int32)
+    elif layout == "chunk":
+        slots = torch.arange(37, 37 + T, dtype=torch.int32, device=DEV)
+    else:
+        slots = torch.cat([torch.randperm(256, device=DEV)[:23].to(torch.int32) + 256,
+                           torch.arange(64, 64 + T - 23, dtype=torch.int32, device=DEV)])
     slots[5] = -1                                                   # padding token: no cache write
     cs = ref.build_cos_sin_cache(4096, 128, 500000.0, DEV)
     ks, vs = (0.05, 0.07) if kv_dtype == torch.float8_e4m3fn else (1.0, 1.0)
