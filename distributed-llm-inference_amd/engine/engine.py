@@ -37,13 +37,26 @@ class LLMEngine:
         self.requests: dict[str, Request] = {}
         self._seq_ids = itertools.count(1)
         self._inflight = None
-        self.async_scheduling = (self.runner.on_gpu if cfg.async_scheduling is None else bool(cfg.async_scheduling))
+        self.async_scheduling = self._default_async() if cfg.async_scheduling is None else bool(cfg.async_scheduling)
         if self.ctx.is_driver:
             self.bm = BlockManager(self.runner.num_blocks, KV_BLOCK_SIZE, cfg.cache.enable_prefix_caching)
             self.scheduler = Scheduler(cfg.sched, self.bm)
         else:
             self.bm = None
             self.scheduler = None
+
+    def _default_async(self) -> bool:
+        """Pipelined stepping is the GPU default.  Under TP it needs stream-ordered collectives (RCCL): the step
+        broadcast is then just another operation on the stream.  gloo moves device tensors through the host and
+        blocks until the stream has drained — with step N's all-reduce kernels still spinning for their peer that
+        wait never ends (seen with Llama-3-8B shapes in the single-GPU rehearsal mode), so gloo groups step
+        one at a time."""
+        if not self.runner.on_gpu:
+            return False
+        if self.ctx.tp_size > 1:
+            import torch.distributed as dist
+            return dist.get_backend(self.ctx.group) == "nccl"
+        return True
 
     # ------------------------------------------------------------------ intake
     def add_request(self, req_id: str, prompt=None, params: Optional[SamplingParams] = None, prompt_ids=None,

@@ -27,6 +27,9 @@ from ..ops.kv_layout import allocate_kv_cache, bytes_per_block
 from ..parallel.state import SINGLE, ParallelContext
 
 
+_DUMP_LOGITS = __import__("os").environ.get("DLI_DUMP_LOGITS", "")
+
+
 def _pinned(shape, dtype, pin):
     t = torch.zeros(shape, dtype=dtype)
     return t.pin_memory() if pin else t
@@ -64,6 +67,7 @@ class ModelRunner:
         self.graph_pool = None
         self.tile_tokens = ops.prefill_tile_tokens(self.local_heads, self.local_kv_heads)
         self.stats = {"graph_steps": 0, "eager_steps": 0}
+        self._dumped = False
 
     # ------------------------------------------------------------------ sizing
     def _decide_num_blocks(self) -> int:
@@ -200,6 +204,9 @@ class ModelRunner:
         if S == 0:
             return
         logits = self.model.compute_logits(h.index_select(0, dv["last"][:S]))
+        if _DUMP_LOGITS and self.ctx.is_driver and not torch.cuda.is_current_stream_capturing() and not self._dumped:
+            self._dumped = True                              # debug aid: first sampled row of the first eager step
+            torch.save(logits[0].float().cpu(), _DUMP_LOGITS)
         ops.sample(logits, dv["temp"][:S], dv["top_p"][:S], dv["top_k"][:S], dv["seeds"][:S], dv["steps"][:S],
                    out=self.d_sampled[:S])
 

@@ -69,9 +69,19 @@ def _die_with_parent(parent_pid: int) -> None:
     threading.Thread(target=watch, daemon=True, name="parent-watchdog").start()
 
 
+def _maybe_dump_stacks_later() -> None:
+    """Debug aid: DLI_DUMP_STACKS_AFTER=<seconds> makes every rank print its Python stacks after that long
+    (where is a hung TP group waiting?)."""
+    sec = int(os.environ.get("DLI_DUMP_STACKS_AFTER", "0") or 0)
+    if sec > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(sec, repeat=True)
+
+
 def _worker_main(cfg: EngineConfig, rank: int, world: int, port: int, base_index: int, parent_pid: int = 0):
     if parent_pid:
         _die_with_parent(parent_pid)
+    _maybe_dump_stacks_later()
     from ..engine.engine import LLMEngine
     ctx, device = _join_group(cfg, rank, world, port, base_index)
     engine = LLMEngine(cfg, ctx, device)
@@ -93,6 +103,7 @@ def maybe_launch_tp(cfg: EngineConfig, base_index: int = 0) -> Optional[Parallel
     tp = cfg.parallel.tp
     if tp <= 1:
         return SINGLE
+    _maybe_dump_stacks_later()
     port = _free_port()
     spawn = mp.get_context("spawn")
     for rank in range(1, tp):

@@ -15,12 +15,14 @@ from dli_amd.runtime.tp_launcher import join_children, maybe_launch_tp
 def main():
     model, tp, ep, backend = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     prompts = json.loads(sys.argv[5])
-    cfg = EngineConfig(model=get_model_config(model), cache=CacheConfig(num_blocks=512),
+    over = {"num_layers": int(os.environ["DLI_TEST_LAYERS"])} if os.environ.get("DLI_TEST_LAYERS") else {}
+    cfg = EngineConfig(model=get_model_config(model, **over), cache=CacheConfig(num_blocks=512),
                        sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=2048,
                                              long_prefill_chunk=2048),
                        parallel=ParallelConfig(tp=tp, ep=ep, backend=backend,
                                                custom_all_reduce=os.environ.get("DLI_NO_CUSTOM_AR") != "1"), device="cuda",
-                       graph_batch_sizes=(4, 8))
+                       graph_batch_sizes=(4, 8),
+                       async_scheduling={"0": False, "1": True}.get(os.environ.get("DLI_TEST_ASYNC", ""), None))
     ctx = maybe_launch_tp(cfg)
     eng = LLMEngine(cfg, ctx)
     eng.warmup()
