@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=2048)
     ap.add_argument("--kv-dtype", default="auto")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--fcfs", action="store_true", help="plain FCFS admission (default: requests past their TTFT deadline yield)")
     ap.add_argument("--sync-steps", action="store_true", help="disable pipelined stepping (one step in flight at a time)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--num-kv-blocks", type=int, default=None, help="fix the KV cache size (default: fill free HBM)")
@@ -96,7 +97,8 @@ def main():
     cfg = EngineConfig(model=mcfg, cache=CacheConfig(kv_dtype=args.kv_dtype, num_blocks=args.num_kv_blocks),
                        sched=SchedulerConfig(max_num_seqs=args.max_num_seqs,
                                              max_num_batched_tokens=args.max_batched_tokens,
-                                             max_model_len=2112, long_prefill_chunk=args.chunk),
+                                             max_model_len=2112, long_prefill_chunk=args.chunk,
+                                             ttft_slo=None if args.fcfs else SLO_TTFT),
                        device="cuda", seed=args.seed, use_hip_graphs=not args.no_graphs,
                        async_scheduling=not args.sync_steps)
     t_load = time.perf_counter()
@@ -152,6 +154,7 @@ def main():
         one_step()
     sync()
     n_done_before = len(done)
+    n_injected_before = nxt
     steps_before = (eng.metrics.steps, eng.metrics.step_tokens, eng.metrics.sched_time, eng.metrics.exec_time,
                     eng.metrics.post_time, dict(eng.runner.stats))
     t_start = time.perf_counter()
@@ -182,6 +185,7 @@ def main():
         "eager_steps": eng.runner.stats["eager_steps"] - steps_before[5]["eager_steps"],
         "running": m.running, "waiting": m.waiting, "kv_used": m.kv_used_frac, "preemptions": m.preemptions,
         "backlog_s": float(time.perf_counter() - t0 - (stamps[nxt - 1] if nxt else 0.0)),
+        "arrived": nxt - n_injected_before, "late_queue": len(eng.scheduler.late),
     }
     if world > 1:
         allstats = [None] * world
@@ -206,10 +210,12 @@ def main():
             "config": {"model": args.model, "global_batch": args.max_num_seqs * world, "seq_len": 2048,
                        "parallelism": f"dp{world}", "offered_qps": args.qps * world, "kv_dtype": args.kv_dtype,
                        "max_num_batched_tokens": args.max_batched_tokens, "chunk": args.chunk,
-                       "pipelined_steps": not args.sync_steps},
+                       "pipelined_steps": not args.sync_steps, "slo_aware_admission": not args.fcfs},
             "requests_finished": finished, "slo_attainment": round(good / max(finished, 1), 4),
             "goodput_interactive_req_per_s": round(sum(s["good_interactive"] for s in allstats) / T, 3),
             "request_throughput": round(finished / T, 3),
+            "arrival_rate_in_window": round(sum(s["arrived"] for s in allstats) / T, 3),
+            "deferred_past_deadline": sum(s["late_queue"] for s in allstats),
             "ttft_p50_s": pct(all_ttft, 50), "ttft_p99_s": pct(all_ttft, 99),
             "tpot_p50_s": pct(all_tpot, 50), "tpot_p99_s": pct(all_tpot, 99),
             "output_tok_per_s": round(sum(s["out_tokens"] for s in allstats) / T, 1),

@@ -115,6 +115,11 @@ class SchedulerConfig:
     # Large steps are trimmed (by shortening one prefill chunk) to a multiple of this many tokens: the GEMMs
     # run on 256-row macro-tiles, and a ragged last tile costs as much as a full one.  0 disables.
     token_alignment: int = 256
+    # SLO-aware admission: a waiting request whose time-to-first-token deadline (arrival + ttft_slo seconds) has
+    # already passed yields to requests that can still make theirs; it is admitted when none of those is waiting.
+    # Under overload FCFS makes EVERY request late (the queue only grows); this keeps goodput at capacity.
+    ttft_slo: Optional[float] = None
+    ttft_slo_margin: float = 0.3            # fraction of ttft_slo kept for the prefill itself (queueing budget = the rest)
 
 
 @dataclass

@@ -96,7 +96,7 @@ class LLMEngine:
 
     @property
     def num_waiting(self) -> int:
-        return len(self.scheduler.waiting)
+        return self.scheduler.num_waiting
 
     def outstanding_tokens(self) -> int:
         """Load figure used by the DP router: tokens still to be computed or generated."""

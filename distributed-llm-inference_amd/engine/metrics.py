@@ -87,7 +87,7 @@ class EngineMetrics:
         self.post_time += t_post
         self.step_time.observe(t_sched + t_exec + t_post)
         sch = engine.scheduler
-        self.running, self.waiting = len(sch.running), len(sch.waiting)
+        self.running, self.waiting = len(sch.running), sch.num_waiting
         self.preemptions = sch.num_preemptions
         bm = engine.bm
         self.kv_used_frac = 1.0 - bm.num_free / bm.num_blocks

@@ -21,6 +21,7 @@ KV accounting lives in the C++ ``BlockManager`` (``csrc/runtime/block_manager.cp
 """
 from __future__ import annotations
 
+import time
 from collections import deque
 from typing import Optional
 
@@ -35,6 +36,7 @@ class Scheduler:
         self.cfg = cfg
         self.bm = block_manager
         self.waiting: deque[Request] = deque()
+        self.late: deque[Request] = deque()                # ttft_slo only: deadline already missed, oldest first
         self.running: list[Request] = []
         self.watermark_blocks = max(int(block_manager.num_blocks * watermark), 1)
         self.num_preemptions = 0
@@ -44,7 +46,7 @@ class Scheduler:
         self.waiting.append(req)
 
     def abort(self, req_id: str, req: Optional[Request] = None) -> Optional[Request]:
-        for q in (self.running, self.waiting):
+        for q in (self.running, self.waiting, self.late):
             for r in q:
                 if r.req_id == req_id:
                     q.remove(r)
@@ -56,7 +58,11 @@ class Scheduler:
         return None
 
     def has_work(self) -> bool:
-        return bool(self.waiting or self.running)
+        return bool(self.waiting or self.running or self.late)
+
+    @property
+    def num_waiting(self) -> int:
+        return len(self.waiting) + len(self.late)
 
     def _release(self, req: Request, status: RequestStatus) -> None:
         self.bm.free_seq(req.seq_id)
@@ -68,6 +74,8 @@ class Scheduler:
                 self.running.remove(req)
             elif req in self.waiting:                      # preempted while its last step was in flight
                 self.waiting.remove(req)
+            elif req in self.late:
+                self.late.remove(req)
         # publish the generated text too: the next turn of a conversation re-sends it as a prefix
         if self.bm.has_seq(req.seq_id):
             self.bm.commit(req.seq_id, req.all_ids, min(req.num_computed, req.num_tokens))
@@ -109,9 +117,15 @@ class Scheduler:
             i += 1
 
         # 2) admission (never in a step that had to preempt)
+        if cfg.ttft_slo is not None and self.waiting:
+            deadline = time.perf_counter() - cfg.ttft_slo * (1.0 - cfg.ttft_slo_margin)
+            while self.waiting and self.waiting[0].arrival < deadline and self.waiting[0].num_output == 0 \
+                    and self.waiting[0].preemptions == 0:
+                self.late.append(self.waiting.popleft())    # arrival order = deadline order: late ones sit at the head
         if not preempted:
-            while self.waiting and budget > 0 and len(self.running) < cfg.max_num_seqs:
-                req = self.waiting[0]
+            while (self.waiting or self.late) and budget > 0 and len(self.running) < cfg.max_num_seqs:
+                queue = self.waiting if self.waiting else self.late
+                req = queue[0]
                 if not self.bm.has_seq(req.seq_id):
                     cached = self.bm.match_prefix(req.seq_id, req.all_ids)
                     req.num_computed = cached
@@ -126,7 +140,7 @@ class Scheduler:
                                                     - len(self.bm.block_table(req.seq_id)), 0)
                 if free_after < self.watermark_blocks or not self.bm.allocate(req.seq_id, need_total):
                     break
-                self.waiting.popleft()
+                queue.popleft()
                 req.status = RequestStatus.RUNNING
                 self.running.append(req)
                 picked.append((req, n_new))

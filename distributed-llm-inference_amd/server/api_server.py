@@ -296,7 +296,7 @@ def engine_config_from_args(a) -> EngineConfig:
         cache=CacheConfig(kv_dtype=a.kv_dtype, num_blocks=a.num_kv_blocks, gpu_memory_utilization=a.gpu_memory_utilization,
                           enable_prefix_caching=not a.no_prefix_caching),
         sched=SchedulerConfig(max_num_seqs=a.max_num_seqs, max_num_batched_tokens=a.max_num_batched_tokens,
-                              max_model_len=a.max_model_len, long_prefill_chunk=a.prefill_chunk),
+                              max_model_len=a.max_model_len, long_prefill_chunk=a.prefill_chunk, ttft_slo=a.ttft_slo),
         parallel=ParallelConfig(tp=a.tp, ep=a.ep, custom_all_reduce=not a.no_custom_all_reduce),
         device=a.device, seed=a.seed, use_hip_graphs=not a.no_hip_graphs, weights_path=a.weights,
         tokenizer_path=a.tokenizer)
@@ -318,6 +318,8 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--max-model-len", type=int, default=4096)
     ap.add_argument("--max-position", type=int, default=None)
     ap.add_argument("--prefill-chunk", type=int, default=2048)
+    ap.add_argument("--ttft-slo", type=float, default=None,
+                    help="seconds; waiting requests already past this time-to-first-token deadline yield to fresher ones")
     ap.add_argument("--no-hip-graphs", action="store_true")
     ap.add_argument("--no-custom-all-reduce", action="store_true")
     ap.add_argument("--seed", type=int, default=0)

@@ -270,3 +270,28 @@ def test_pipelined_stepping_with_preemption_and_abort():
     for i in a_fin:
         assert a_out[i] == b_out[i] and a_fin[i] == b_fin[i]
     assert set(a_fin) == set(b_fin) == set(range(10)) - {1}
+
+
+def test_slo_aware_admission_serves_requests_that_can_still_make_their_deadline_first():
+    import time
+    eng = make_engine(max_seqs=1)
+    eng.cfg.sched.ttft_slo = 0.5
+    now = time.perf_counter()
+    p = SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True)
+    late = eng.add_request("late", prompt_ids=[5, 6, 7], params=p, arrival=now - 5.0)       # deadline long gone
+    fresh = eng.add_request("fresh", prompt_ids=[8, 9, 10], params=p, arrival=now)
+    order = []
+    while eng.has_unfinished():
+        for o in eng.step():
+            if o.finished:
+                order.append(o.req_id)
+    assert order == ["fresh", "late"]                     # the late one is not dropped, it yields
+    assert late.first_scheduled > fresh.first_scheduled and eng.num_waiting == 0
+    # FCFS without the option
+    eng2 = make_engine(max_seqs=1)
+    eng2.add_request("late", prompt_ids=[5, 6, 7], params=p, arrival=now - 5.0)
+    eng2.add_request("fresh", prompt_ids=[8, 9, 10], params=p, arrival=now)
+    order2 = []
+    while eng2.has_unfinished():
+        order2 += [o.req_id for o in eng2.step() if o.finished]
+    assert order2 == ["late", "fresh"]
