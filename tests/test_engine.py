@@ -275,10 +275,10 @@ def test_pipelined_stepping_with_preemption_and_abort():
 def test_slo_aware_admission_serves_requests_that_can_still_make_their_deadline_first():
     import time
     eng = make_engine(max_seqs=1)
-    eng.cfg.sched.ttft_slo = 0.5
+    eng.cfg.sched.ttft_slo = 60.0                          # far from anything a loaded box could consume
     now = time.perf_counter()
     p = SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True)
-    late = eng.add_request("late", prompt_ids=[5, 6, 7], params=p, arrival=now - 5.0)       # deadline long gone
+    late = eng.add_request("late", prompt_ids=[5, 6, 7], params=p, arrival=now - 500.0)     # deadline long gone
     fresh = eng.add_request("fresh", prompt_ids=[8, 9, 10], params=p, arrival=now)
     order = []
     while eng.has_unfinished():
@@ -289,7 +289,7 @@ def test_slo_aware_admission_serves_requests_that_can_still_make_their_deadline_
     assert late.first_scheduled > fresh.first_scheduled and eng.num_waiting == 0
     # FCFS without the option
     eng2 = make_engine(max_seqs=1)
-    eng2.add_request("late", prompt_ids=[5, 6, 7], params=p, arrival=now - 5.0)
+    eng2.add_request("late", prompt_ids=[5, 6, 7], params=p, arrival=now - 500.0)
     eng2.add_request("fresh", prompt_ids=[8, 9, 10], params=p, arrival=now)
     order2 = []
     while eng2.has_unfinished():
