@@ -50,9 +50,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=1500)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--model", default="llama3-8b")
-    ap.add_argument("--qps", type=float, default=float(os.environ.get("DLI_BENCH_QPS", "56")),
+    ap.add_argument("--qps", type=float, default=float(os.environ.get("DLI_BENCH_QPS", "68")),
                     help="offered load per GPU (requests/s)")
-    ap.add_argument("--ramp-seconds", type=float, default=12.0)
+    ap.add_argument("--ramp-seconds", type=float, default=30.0,
+                    help="untimed replay before the window: ~2 request lifetimes, so that the in-flight population is steady")
     ap.add_argument("--max-num-seqs", type=int, default=2048)
     ap.add_argument("--max-batched-tokens", type=int, default=4096)
     ap.add_argument("--chunk", type=int, default=2048)

@@ -71,6 +71,8 @@ def make_burstgpt(path: str | None = None, n: int = 2000, mean_qps: float = 2.0,
         i += 1
     stamps = np.cumsum(gaps)
     stamps -= stamps[0]
+    if n > 1 and stamps[-1] > 0:
+        stamps *= ((n - 1) / mean_qps) / stamps[-1]       # the compressed bursts shorten the trace: restore the mean rate
     req = _lengths(rng, n, median=420, sigma=1.0, lo=4, hi=8000)
     resp = _lengths(rng, n, median=210, sigma=0.9, lo=1, hi=2000)
     df = pd.DataFrame({
