@@ -92,13 +92,21 @@ __device__ __forceinline__ bf16x8 load_v(const void* page, int n, int col, int g
   }
 }
 
-__device__ __forceinline__ float group_max(float v) {   // over the 4 lane groups sharing a column
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions over the 4 lanes (l, l^16, l^32, l^48) that share a query column, with the gfx950 row-swap VALU
+// instructions instead of LDS-crossbar shuffles.  v_permlane16_swap(x, x) returns (rows 0,0,2,2 / rows 1,1,3,3) of
+// x, v_permlane32_swap(x, x) returns (upper half twice / lower half twice): in every lane one of the two results
+// is the lane's own value and the other its partner's, so max3 / a plain sum of the pair needs no select.
+__device__ __forceinline__ float group_max(float v) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(v, fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(v, fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1])));
 }
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // One 32-token page against one query-column set: Sᵀ → online softmax → Pᵀ fragment.
