@@ -69,8 +69,12 @@ class RoutingPolicy:
     """Pure decision logic (unit-testable without sockets)."""
 
     def __init__(self, replicas: list[Replica], affinity_slack: float = 0.5, slack_tokens: int = 4096,
-                 table_size: int = 200_000):
+                 table_size: int = 200_000, stateless_affinity: bool = False):
         self.replicas = replicas
+        # several router workers (``--workers``) do not share this table: with ``stateless_affinity`` a prompt or
+        # session unknown to THIS worker goes to the replica every worker would pick (rendezvous hash of its first
+        # prefix block / session id over the live replicas), so that follow-up turns still find their KV pages
+        self.stateless_affinity = stateless_affinity
         self.affinity_slack = affinity_slack
         self.slack_tokens = slack_tokens
         self.table: OrderedDict[int, int] = OrderedDict()      # prefix-chain hash / session key → replica index
@@ -98,6 +102,9 @@ class RoutingPolicy:
                 cand = self.table.get(key)
                 if cand is not None:
                     break
+        if cand is None and self.stateless_affinity and (session is not None or chain):
+            key = zlib.crc32(session.encode()) if session is not None else chain[0]
+            cand = max(alive, key=lambda i: zlib.crc32(i.to_bytes(2, "little"), key & 0xFFFFFFFF))
         if cand is not None and cand in alive:
             lb, lc = self.replicas[best].load(), self.replicas[cand].load()
             if lc <= lb * (1.0 + self.affinity_slack) + self.slack_tokens:
@@ -324,6 +331,8 @@ def main(argv=None):
     ap.add_argument("--port", type=int, default=11434)
     ap.add_argument("--affinity-slack", type=float, default=0.5)
     ap.add_argument("--cpu", action="store_true", help="spawned replicas run on CPU (plumbing tests)")
+    ap.add_argument("--workers", type=int, default=1,
+                    help="router processes sharing the port (SO_REUSEPORT); one relays roughly 100 k streamed lines/s")
     a, server_args = ap.parse_known_args(argv)
     procs = []
     if a.spawn:
@@ -334,10 +343,22 @@ def main(argv=None):
         urls = [u for u in a.replicas.split(",") if u]
     if not urls:
         ap.error("give --replicas or --spawn")
-    router = Router(urls, affinity_slack=a.affinity_slack)
+    def serve():
+        router = Router(urls, affinity_slack=a.affinity_slack, stateless_affinity=a.workers > 1)
+        web.run_app(router.app(), host=a.host, port=a.port, access_log=None, backlog=4096, reuse_port=a.workers > 1,
+                    print=None if a.workers > 1 else print)
+
+    workers = []
     try:
-        web.run_app(router.app(), host=a.host, port=a.port, access_log=None, backlog=4096)
+        if a.workers > 1:
+            import multiprocessing as mp
+            workers = [mp.get_context("fork").Process(target=serve, daemon=True) for _ in range(a.workers - 1)]
+            for w in workers:
+                w.start()
+        serve()
     finally:
+        for w in workers:
+            w.terminate()
         for p in procs:
             p.terminate()
 

@@ -90,3 +90,27 @@ def test_router_end_to_end_two_replicas_affinity_and_failover():
             await rr.cleanup()
             await r2.cleanup()
     asyncio.run(go())
+
+
+def test_stateless_affinity_is_consistent_across_router_workers():
+    """Two router workers (separate tables) must send an unknown session / prompt prefix to the same replica."""
+    from dli_amd.router.router import Replica, RoutingPolicy, prefix_chain
+    mk = lambda: RoutingPolicy([Replica(f"http://r{i}") for i in range(8)], stateless_affinity=True)
+    a, b = mk(), mk()
+    picks = set()
+    for k in range(50):
+        chain = prefix_chain(f"conversation {k} " * 40)
+        pa, pb = a.choose(chain), b.choose(chain)
+        assert pa == pb
+        assert a.choose([], session=f"s{k}") == b.choose([], session=f"s{k}")
+        picks.add(pa)
+    assert len(picks) >= 5                                   # spread over the replicas, not one hot spot
+    # an overloaded target still yields to the least-loaded replica
+    chain = prefix_chain("conversation 0 " * 40)
+    target = a.choose(chain)
+    a.replicas[target].outstanding_tokens = 10_000_000
+    assert a.choose(chain) != target
+    # and a dead one is skipped consistently
+    a.replicas[target].outstanding_tokens = 0
+    a.replicas[target].healthy = b.replicas[target].healthy = False
+    assert a.choose(chain) == b.choose(chain) != target
