@@ -24,35 +24,35 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int MOE_MAX_E = 64;
 
 // ------------------------------------------------------------------------------------------ routing
-__global__ void moe_route_kernel(const uint16_t* __restrict__ logits, int T, int E, int K, int* __restrict__ ids,
-                                 float* __restrict__ weights) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  float v[MOE_MAX_E];
-  float mx = -3.0e38f;
-  for (int e = 0; e < E; ++e) {
-    v[e] = bf2f(logits[(int64_t)t * E + e]);
-    mx = fmaxf(mx, v[e]);
-  }
-  float sum = 0.f;
-  for (int e = 0; e < E; ++e) {
-    v[e] = __expf(v[e] - mx);
-    sum += v[e];
-  }
-  float picked = 0.f;
+// One wave per token, one lane per expert (E ≤ 64): softmax numerators in registers, K rounds of a wave-wide
+// arg-max (ties → lowest expert id, like torch.topk on the reference path), lane k keeps the k-th pick.
+__global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restrict__ logits, int T, int E, int K,
+                                                        int* __restrict__ ids, float* __restrict__ weights) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (t >= T) return;                                   // whole wave
+  const float v = lane < E ? bf2f(logits[(int64_t)t * E + lane]) : -3.0e38f;
+  const float mx = wave_max(v);
+  float p = lane < E ? __expf(v - mx) : -1.f;           // the softmax denominator cancels in the renormalisation
+  float picked = 0.f, my_w = 0.f;
+  int my_id = 0;
   for (int k = 0; k < K; ++k) {
-    int best = 0;
-    float bv = -1.f;
-    for (int e = 0; e < E; ++e)
-      if (v[e] > bv) { bv = v[e]; best = e; }
-    ids[t * K + k] = best;
-    weights[t * K + k] = bv;
+    float bv = p;
+    int bi = lane;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == k) { my_id = bi; my_w = bv; }
     picked += bv;
-    v[best] = -2.f;
+    if (lane == bi) p = -2.f;
   }
-  const float inv = 1.f / picked;      // renormalise over the chosen experts (softmax denominator cancels)
-  for (int k = 0; k < K; ++k) weights[t * K + k] *= inv;
-  (void)sum;
+  if (lane < K) {
+    ids[t * K + lane] = my_id;
+    weights[t * K + lane] = my_w / picked;              // renormalise over the chosen experts
+  }
 }
 
 // ------------------------------------------------------------------------------------------ alignment
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void moe_sum_kernel(const void* __restrict__ y
 // ------------------------------------------------------------------------------------------ launchers
 void launch_moe_route(const void* logits, int T, int E, int K, int* ids, float* weights, hipStream_t stream) {
   if (T == 0) return;
-  hipLaunchKernelGGL(moe_route_kernel, dim3((T + 127) / 128), dim3(128), 0, stream, (const uint16_t*)logits, T, E, K, ids, weights);
+  hipLaunchKernelGGL(moe_route_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, (const uint16_t*)logits, T, E, K, ids, weights);
 }
 
 void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int* sorted_ids, int* tile_expert, int* meta,
