@@ -190,6 +190,30 @@ def bench_moe(quick):
         report("fused_moe", t, flops=2 * rows * 3 * I * H, bytes_=El * 3 * I * H * 2, T=T, local_experts=El)
 
 
+def bench_linear(quick):
+    """Decode-sized linear layers: the weight-streaming kernel against the library GEMM (hipBLASLt via torch).
+    Weights rotate through ≥ 1 GB of copies so that no call finds its matrix in the 256 MB infinity cache."""
+    import torch.nn.functional as F
+    shapes = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 128256, 4096)]
+    for name, N, K in (shapes[1:4] if quick else shapes):
+        copies = max(2, -(-(1 << 30) // (N * K * 2)))
+        ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(copies)]
+        for M in ((1, 16) if quick else (1, 4, 8, 16)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            state = {"i": 0}
+
+            def call(fn):
+                def run():
+                    state["i"] = (state["i"] + 1) % copies
+                    return fn(x, ws[state["i"]])
+                return run
+            t_lib = timeit(call(lambda a, w: F.linear(a, w)), iters=4 * copies, warmup=copies)
+            t_sk = timeit(call(lambda a, w: ops.linear(a, w)), iters=4 * copies, warmup=copies)
+            report("linear(" + name + ")", t_sk, bytes_=N * K * 2, M=M, N=N, K=K, library_us=round(t_lib * 1e6, 2),
+                   speedup=round(t_lib / t_sk, 2))
+        del ws
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
@@ -214,6 +238,8 @@ def main():
         bench_sampler(a.quick)
     if run("moe"):
         bench_moe(a.quick)
+    if run("linear"):
+        bench_linear(a.quick)
 
 
 if __name__ == "__main__":

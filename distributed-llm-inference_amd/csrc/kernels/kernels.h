@@ -26,6 +26,8 @@ void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, 
                           const int* tile_seq, const int* tile_q0, int num_tiles, void* out, int64_t out_stride, int Hq,
                           int Hkv, float scale, bool kv_fp8, float k_scale, float v_scale, hipStream_t stream);
 
+void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
+                          int M, int N, int K, hipStream_t stream);
 void launch_gather_sampled(int* input, const int* src, const int64_t* sampled, int n, hipStream_t stream);
 void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int B, int V, const float* temperature,
                    const float* top_p, const int* top_k, const int64_t* seeds, const int64_t* steps, const float* noise,

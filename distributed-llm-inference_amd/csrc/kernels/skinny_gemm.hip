@@ -1,0 +1,135 @@
+// K10: decode-sized linear layer, y[M,N] = x[M,K] · W[N,K]ᵀ (+ bias) for M ≤ 16.
+//
+// At M ≤ 16 the layer is a pure stream of W through the chip (2·N·K bytes, ≈ 0 reuse), so the kernel is built
+// around HBM, not around the matrix cores: the product is computed transposed, yᵀ = W · xᵀ, with W as the MFMA
+// A operand (16 weight rows per v_mfma_f32_16x16x32_bf16) and the ≤ 16 tokens as the 16 B columns — one MFMA
+// per KiB of weights, far below the MFMA roof.
+//
+// What decides the speed is the SHAPE of the global reads.  Loading the A fragments directly (lane = row l&15,
+// 16 bytes at k-chunk l>>4) touches 16 rows × 64 B per wave instruction and measured 3.6–4.6 TB/s; rows read in
+// 256-byte runs measured 5.2–5.9 TB/s.  So operands go through LDS: a wave fetches a 16-row × 128-k tile with four
+// LDS-DMA instructions (global_load_lds, 16 lanes × 16 B = 256 contiguous bytes of each of 4 rows, no VGPRs), and
+// reads the MFMA fragments back with ds_read_b128.  One DMA instruction fills 1 KiB of LDS in lane order, so the
+// bank swizzle is applied on the source side: LDS chunk p of tile row t holds global 16-byte chunk p ^ t; the
+// fragment read of chunk c = 4j + (l>>4) of row t = l&15 goes to slot c ^ t, which is conflict-free for the
+// 16-lane groups of ds_read_b128.  The activations take the same path as a 17th "row tile" (rows ≥ M repeat the
+// last token; those output columns are never stored), so every tile of the ring has the same shape.
+//
+// A 256-thread workgroup owns 16 weight rows; its 4 waves split K between them in interleaved 128-element
+// slabs, each wave double-buffers its slabs in a private LDS ring (no barriers in the loop: the wave waits on its
+// own vmcnt), the 4 partial accumulators meet in LDS at the end and the sum is written as bf16.
+#include "common.h"
+#include "kernels.h"
+
+namespace dli {
+
+constexpr int SK_WAVES = 4;
+constexpr int SK_TILE = 4096;    // bytes: 16 rows × 128 bf16
+
+// XI = DMA instructions spent on the activation tile (4 token rows each): M ≤ 4 needs one, M ≤ 8 two.  A ring
+// slot is XI KiB of activations followed by the 4 KiB weight tile.  (Two weight row tiles per workgroup — half the
+// activation traffic — measured 20–30 % SLOWER on every Llama shape: fewer, fatter workgroups per CU.)
+template <int XI>
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
+                                                                      const uint16_t* __restrict__ w,
+                                                                      const uint16_t* __restrict__ bias,
+                                                                      uint16_t* __restrict__ out, int64_t out_stride,
+                                                                      int M, int N, int K) {
+  constexpr int SLOT = XI * 1024 + SK_TILE;           // bytes per slab: activations + weight tile
+  constexpr int XROWS = 4 * XI;
+  extern __shared__ __attribute__((aligned(1024))) char sk_smem[];   // [wave][2 slots][SLOT]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+
+  // DMA sources: instruction i of a tile covers tile rows 4i + (lane>>4); this lane supplies LDS chunk p = lane&15,
+  // i.e. global chunk p ^ row
+  const char* xsrc[XI];
+  const char* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * i + g, chunk = (r ^ row) << 4;
+    if (i < XI) xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)min(row, M - 1) * x_stride) + chunk;
+    wsrc[i] = reinterpret_cast<const char*>(w + (int64_t)(n0 + row) * K) + chunk;
+  }
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+  char* ring = sk_smem + wave * (2 * SLOT);
+#define DLI_SK_ISSUE(slab_, slot_)                                                                                 \
+  {                                                                                                                \
+    char* dst_ = ring + (slot_) * SLOT;                                                                            \
+    const int64_t kb_ = (int64_t)(slab_) * 256;                                                                    \
+    _Pragma("unroll") for (int i = 0; i < XI; ++i)                                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + kb_), (lptr_t)(dst_ + i * 1024), 16, 0, 0);            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kb_), (lptr_t)(dst_ + (XI + i) * 1024), 16, 0, 0);     \
+  }
+
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n_it = K >> 7;
+  int frag_off[4], xfrag_off[4];                       // this lane's fragment j inside a weight / activation tile
+  const int xr = r & (XROWS - 1);                      // columns ≥ XROWS alias loaded rows (never stored)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    frag_off[j] = XI * 1024 + r * 256 + (((4 * j + g) ^ r) << 4);
+    xfrag_off[j] = xr * 256 + (((4 * j + g) ^ xr) << 4);
+  }
+
+  if (wave < n_it) DLI_SK_ISSUE(wave, 0);
+  int slot = 0;
+  for (int it = wave; it < n_it; it += SK_WAVES, slot ^= 1) {
+    // the other slot was consumed by the MFMAs of the previous iteration (they waited for its ds_reads)
+    if (it + SK_WAVES < n_it) {
+      DLI_SK_ISSUE(it + SK_WAVES, slot ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + 4) : "memory");     // everything but the slab just issued
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* base = ring + slot * SLOT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + xfrag_off[j]);
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(base + frag_off[j]);
+      acc = mfma16(wf, xf, acc);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers before the slot is refilled
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef DLI_SK_ISSUE
+
+  // lane holds yᵀ[n = 4g + j][m = r]; the ring is dead once every wave is past its loop
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(sk_smem);      // [wave][256]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[wave * 256 + j * 64 + lane] = acc[j];
+  __syncthreads();
+  {
+    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;   // consecutive threads → consecutive n of one token
+    if (m < M) {
+      const int src = (nn & 3) * 64 + (nn >> 2) * 16 + m;
+      float s = 0.f;
+#pragma unroll
+      for (int wv_ = 0; wv_ < SK_WAVES; ++wv_) s += red[wv_ * 256 + src];
+      const int n = n0 + nn;
+      if (bias != nullptr) s += bf2f(bias[n]);
+      out[(int64_t)m * out_stride + n] = f2bf(s);
+    }
+  }
+}
+
+template <int XI>
+static void launch_skinny(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
+                          int M, int N, int K, hipStream_t stream) {
+  constexpr int lds = SK_WAVES * 2 * (XI * 1024 + SK_TILE);        // 40 / 48 / 64 KiB: 2–4 workgroups per CU
+  hipLaunchKernelGGL(skinny_linear_kernel<XI>, dim3(N / 16), dim3(SK_WAVES * 64), lds, stream, (const uint16_t*)x, x_stride,
+                     (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, out_stride, M, N, K);
+}
+
+void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
+                          int M, int N, int K, hipStream_t stream) {
+  if (M <= 4) launch_skinny<1>(out, out_stride, x, x_stride, w, bias, M, N, K, stream);
+  else if (M <= 8) launch_skinny<2>(out, out_stride, x, x_stride, w, bias, M, N, K, stream);
+  else launch_skinny<4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream);
+}
+
+}  // namespace dli

@@ -54,6 +54,25 @@ Tensor silu_and_mul(const Tensor& x) {
   return out;
 }
 
+// y = x · Wᵀ (+ bias) for decode-sized x (≤ 16 rows): the weight-streaming kernel in kernels/skinny_gemm.hip
+Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias) {
+  check_bf16_rows(x, "x");
+  const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
+  TORCH_CHECK(M >= 1 && M <= 16, "skinny_linear: 1..16 rows, got ", M);
+  TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
+              "skinny_linear: weight must be a contiguous bf16 [N, K] GPU tensor with K = ", K);
+  TORCH_CHECK(K % 128 == 0 && N % 16 == 0 && reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0,
+              "skinny_linear: K % 128 == 0 and N % 16 == 0 required, got N=", N, " K=", K);
+  const void* b = nullptr;
+  if (bias.has_value()) {
+    TORCH_CHECK(bias->is_cuda() && bias->scalar_type() == at::kBFloat16 && bias->is_contiguous() && bias->numel() == N);
+    b = bias->data_ptr();
+  }
+  Tensor out = at::empty({M, N}, x.options());
+  dli::launch_skinny_linear(out.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), b, (int)M, (int)N, (int)K, cur_stream(x));
+  return out;
+}
+
 void check_cache(const Tensor& k_cache, const Tensor& v_cache, int64_t Hkv) {
   TORCH_CHECK(k_cache.is_cuda() && v_cache.is_cuda() && k_cache.is_contiguous() && v_cache.is_contiguous());
   TORCH_CHECK(k_cache.scalar_type() == v_cache.scalar_type() && (k_cache.scalar_type() == at::kBFloat16 || is_fp8(k_cache)),
@@ -277,6 +296,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
+  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias) -> Tensor", &skinny_linear);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
         "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale) -> ()", &rope_and_cache);
   m.def("copy_pages(Tensor(a!) cache, Tensor pairs) -> ()", &copy_pages);

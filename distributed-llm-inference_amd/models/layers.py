@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..parallel.state import ParallelContext
 
 
@@ -84,7 +85,7 @@ class ColumnParallelLinear(nn.Module):
         self.bias = Weight((sum(out_segments),), 0, ctx, dtype, device, segments=list(out_segments)) if bias else None
 
     def forward(self, x):
-        return F.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
+        return ops.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
 
 
 class RowParallelLinear(nn.Module):
@@ -113,7 +114,7 @@ class RowParallelLinear(nn.Module):
         if (self.reduce and self.ctx.tp_size > 1 and x.is_cuda and x.dim() == 2 and x.shape[0] >= self.OVERLAP_MIN_ROWS
                 and self._stream_ordered_backend() and not torch.cuda.is_current_stream_capturing()):
             return self._forward_overlapped(x, b)
-        y = F.linear(x, self.weight.data, b)
+        y = ops.linear(x, self.weight.data, b)
         return self.ctx.all_reduce(y) if self.reduce else y
 
     def _stream_ordered_backend(self) -> bool:
@@ -169,7 +170,7 @@ class ReplicatedLinear(nn.Module):
         self.bias = Weight((out_features,), None, ctx, dtype, device) if bias else None
 
     def forward(self, x):
-        return F.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
+        return ops.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
 
 
 class VocabParallelEmbedding(nn.Module):
@@ -205,5 +206,5 @@ class ParallelLMHead(nn.Module):
 
     def forward(self, h: torch.Tensor) -> torch.Tensor:
         w = self._embedding[0].weight.data if self.tied else self.weight.data
-        logits = self.ctx.all_gather_last_dim(F.linear(h, w))
+        logits = self.ctx.all_gather_last_dim(ops.linear(h, w))
         return logits[..., :self.vocab_size] if logits.shape[-1] != self.vocab_size else logits

@@ -113,6 +113,19 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     return ref.silu_and_mul_ref(x)
 
 
+SKINNY_MAX_ROWS = 0 if os.environ.get("DLI_NO_SKINNY_GEMM") else 16
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ weightᵀ + bias``.  Decode-sized GPU inputs (≤ 16 rows) take the weight-streaming MFMA kernel
+    (``csrc/kernels/skinny_gemm.hip``); everything else is a plain library GEMM (hipBLASLt through torch)."""
+    if (x.is_cuda and x.dim() == 2 and x.shape[0] <= SKINNY_MAX_ROWS and x.shape[0] > 0 and x.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] % 128 == 0
+            and weight.shape[0] % 16 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+        return hip().skinny_linear(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
 def rope_and_cache(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: Optional[torch.Tensor],
                    slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                    num_heads: int, num_kv_heads: int, head_dim: int,
