@@ -180,14 +180,15 @@ def bench_sampler(quick):
 
 def bench_moe(quick):
     H, I, E = 4096, 14336, 8
-    for T, El in ([(256, 8)] if quick else [(64, 8), (256, 8), (256, 1), (512, 8), (1024, 8), (4096, 8), (4096, 1)]):
+    for T, El in ([(256, 8)] if quick else [(1, 8), (4, 8), (8, 8), (16, 8), (16, 1), (32, 8), (64, 8), (256, 8), (256, 1), (512, 8), (1024, 8), (4096, 8), (4096, 1)]):
         x = torch.randn(T, H, device=DEV).bfloat16()
         logits = torch.randn(T, E, device=DEV).bfloat16()
         w13 = (torch.randn(El, 2 * I, H, device=DEV) * 0.02).bfloat16()
         w2 = (torch.randn(El, H, I, device=DEV) * 0.02).bfloat16()
         t = timeit(lambda: ops.fused_moe(x, logits, w13, w2, 2, 0), iters=10)
         rows = T * 2 * El / E                                   # expected rows hitting local experts
-        report("fused_moe", t, flops=2 * rows * 3 * I * H, bytes_=El * 3 * I * H * 2, T=T, local_experts=El)
+        hit = int((torch.topk(logits.float(), 2, dim=-1).indices.unique() < El).sum())   # experts whose weights are read
+        report("fused_moe", t, flops=2 * rows * 3 * I * H, bytes_=hit * 3 * I * H * 2, T=T, local_experts=El, experts_hit=hit)
 
 
 def bench_linear(quick):

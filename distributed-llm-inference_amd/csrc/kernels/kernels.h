@@ -28,6 +28,9 @@ void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, 
 
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, hipStream_t stream);
+void launch_moe_skinny(bool down, const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride,
+                       const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
+                       void* out, int64_t out_stride, int K, int N, int max_tiles, int max_rows, hipStream_t stream);
 void launch_gather_sampled(int* input, const int* src, const int64_t* sampled, int n, hipStream_t stream);
 void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int B, int V, const float* temperature,
                    const float* top_p, const int* top_k, const int64_t* seeds, const int64_t* steps, const float* noise,

@@ -25,36 +25,24 @@ namespace dli {
 
 constexpr int SK_WAVES = 4;
 constexpr int SK_TILE = 4096;    // bytes: 16 rows × 128 bf16
+constexpr int MOE_BM = 128;      // rows per expert tile of moe_align (moe.hip: BM)
 
 // XI = DMA instructions spent on the activation tile (4 token rows each): M ≤ 4 needs one, M ≤ 8 two.  A ring
 // slot is XI KiB of activations followed by the 4 KiB weight tile.  (Two weight row tiles per workgroup — half the
 // activation traffic — measured 20–30 % SLOWER on every Llama shape: fewer, fatter workgroups per CU.)
+//
+// The streaming loop + cross-wave reduction, shared by the dense and the MoE kernels.  xsrc[i] / wsrc[i]: this
+// lane's source of DMA instruction i (tile row 4i + (lane>>4), swizzled chunk already added) at k = 0.
+// Returns to thread t the sum for token m = t>>4 and weight row (t&15) of the tile.
 template <int XI>
-__global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
-                                                                      const uint16_t* __restrict__ w,
-                                                                      const uint16_t* __restrict__ bias,
-                                                                      uint16_t* __restrict__ out, int64_t out_stride,
-                                                                      int M, int N, int K) {
+__device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const char* const (&wsrc)[4], int K, char* smem) {
   constexpr int SLOT = XI * 1024 + SK_TILE;           // bytes per slab: activations + weight tile
   constexpr int XROWS = 4 * XI;
-  extern __shared__ __attribute__((aligned(1024))) char sk_smem[];   // [wave][2 slots][SLOT]
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16;
-
-  // DMA sources: instruction i of a tile covers tile rows 4i + (lane>>4); this lane supplies LDS chunk p = lane&15,
-  // i.e. global chunk p ^ row
-  const char* xsrc[XI];
-  const char* wsrc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 4 * i + g, chunk = (r ^ row) << 4;
-    if (i < XI) xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)min(row, M - 1) * x_stride) + chunk;
-    wsrc[i] = reinterpret_cast<const char*>(w + (int64_t)(n0 + row) * K) + chunk;
-  }
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
-  char* ring = sk_smem + wave * (2 * SLOT);
+  char* ring = smem + wave * (2 * SLOT);              // [wave][2 slots][SLOT]
 #define DLI_SK_ISSUE(slab_, slot_)                                                                                 \
   {                                                                                                                \
     char* dst_ = ring + (slot_) * SLOT;                                                                            \
@@ -99,20 +87,87 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint
 
   // lane holds yᵀ[n = 4g + j][m = r]; the ring is dead once every wave is past its loop
   __syncthreads();
-  float* red = reinterpret_cast<float*>(sk_smem);      // [wave][256]
+  float* red = reinterpret_cast<float*>(smem);         // [wave][256]
 #pragma unroll
   for (int j = 0; j < 4; ++j) red[wave * 256 + j * 64 + lane] = acc[j];
   __syncthreads();
-  {
-    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;   // consecutive threads → consecutive n of one token
-    if (m < M) {
-      const int src = (nn & 3) * 64 + (nn >> 2) * 16 + m;
-      float s = 0.f;
+  const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;     // consecutive threads → consecutive n of one token
+  const int src = (nn & 3) * 64 + (nn >> 2) * 16 + m;
+  float s = 0.f;
 #pragma unroll
-      for (int wv_ = 0; wv_ < SK_WAVES; ++wv_) s += red[wv_ * 256 + src];
-      const int n = n0 + nn;
-      if (bias != nullptr) s += bf2f(bias[n]);
-      out[(int64_t)m * out_stride + n] = f2bf(s);
+  for (int wv_ = 0; wv_ < SK_WAVES; ++wv_) s += red[wv_ * 256 + src];
+  return s;
+}
+
+template <int XI>
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
+                                                                      const uint16_t* __restrict__ w,
+                                                                      const uint16_t* __restrict__ bias,
+                                                                      uint16_t* __restrict__ out, int64_t out_stride,
+                                                                      int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(1024))) char sk_smem[];
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  // DMA sources: instruction i of a tile covers tile rows 4i + (lane>>4); this lane supplies LDS chunk p = lane&15,
+  // i.e. global chunk p ^ row.  Rows ≥ M repeat the last token.
+  const char* xsrc[XI];
+  const char* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * i + g, chunk = (r ^ row) << 4;
+    if (i < XI) xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)min(row, M - 1) * x_stride) + chunk;
+    wsrc[i] = reinterpret_cast<const char*>(w + (int64_t)(n0 + row) * K) + chunk;
+  }
+  float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
+  const int m = threadIdx.x >> 4, n = n0 + (threadIdx.x & 15);
+  if (m < M) {
+    if (bias != nullptr) s += bf2f(bias[n]);
+    out[(int64_t)m * out_stride + n] = f2bf(s);
+  }
+}
+
+// MoE at decode size (T ≤ 16 tokens, so every expert sees ≤ 16 rows): one row tile per (weight row tile, expert
+// tile of moe_align).  DOWN = false: gate/up projection, activations gathered by token (sorted id / top_k), raw
+// result to gu[tile·16 + m][N].  DOWN = true: activations act[tile·16 + m][K], result scaled by the routing weight
+// and stored at its (token, slot) row y[sorted id][N] for moe_sum.
+template <int XI, bool DOWN>
+__global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_t* __restrict__ a, int64_t a_stride,
+                                                                   const uint16_t* __restrict__ w, int64_t w_expert_stride,
+                                                                   const int* __restrict__ sorted_ids,
+                                                                   const int* __restrict__ tile_expert,
+                                                                   const int* __restrict__ meta,
+                                                                   const float* __restrict__ topk_w, int top_k,
+                                                                   uint16_t* __restrict__ out, int64_t out_stride, int K) {
+  extern __shared__ __attribute__((aligned(1024))) char sk_smem[];
+  const int tile = blockIdx.y;
+  if (tile >= meta[0]) return;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int* sids = sorted_ids + tile * MOE_BM;
+  int M = 0;                                           // valid rows are packed at the front of the tile
+#pragma unroll
+  for (int i = 0; i < 16; ++i) M += sids[i] >= 0;
+  const uint16_t* we = w + (int64_t)tile_expert[tile] * w_expert_stride;
+  const char* xsrc[XI];
+  const char* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * i + g, chunk = (r ^ row) << 4;
+    if (i < XI) {
+      const int rr = min(row, M - 1);
+      const int64_t arow = DOWN ? (int64_t)tile * 16 + rr : sids[rr] / top_k;
+      xsrc[i] = reinterpret_cast<const char*>(a + arow * a_stride) + chunk;
+    }
+    wsrc[i] = reinterpret_cast<const char*>(we + (int64_t)(n0 + row) * K) + chunk;
+  }
+  const float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
+  const int m = threadIdx.x >> 4, n = n0 + (threadIdx.x & 15);
+  if (m < M) {
+    if (DOWN) {
+      const int sid = sids[m];
+      out[(int64_t)sid * out_stride + n] = f2bf(s * topk_w[sid]);
+    } else {
+      out[((int64_t)tile * 16 + m) * out_stride + n] = f2bf(s);
     }
   }
 }
@@ -130,6 +185,31 @@ void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t 
   if (M <= 4) launch_skinny<1>(out, out_stride, x, x_stride, w, bias, M, N, K, stream);
   else if (M <= 8) launch_skinny<2>(out, out_stride, x, x_stride, w, bias, M, N, K, stream);
   else launch_skinny<4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream);
+}
+
+template <int XI, bool DOWN>
+static void launch_moe_skinny_x(const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride, const int* sorted_ids,
+                                const int* tile_expert, const int* meta, const float* topk_w, int top_k, void* out,
+                                int64_t out_stride, int K, int N, int max_tiles, hipStream_t stream) {
+  constexpr int lds = SK_WAVES * 2 * (XI * 1024 + SK_TILE);
+  hipLaunchKernelGGL((moe_skinny_kernel<XI, DOWN>), dim3(N / 16, max_tiles), dim3(SK_WAVES * 64), lds, stream,
+                     (const uint16_t*)a, a_stride, (const uint16_t*)w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w,
+                     top_k, (uint16_t*)out, out_stride, K);
+}
+
+// max_rows: upper bound of rows per expert (= T): picks how many activation rows a slab carries
+void launch_moe_skinny(bool down, const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride,
+                       const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
+                       void* out, int64_t out_stride, int K, int N, int max_tiles, int max_rows, hipStream_t stream) {
+#define DLI_MS(XI_)                                                                                                      \
+  (down ? launch_moe_skinny_x<XI_, true>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, \
+                                         out_stride, K, N, max_tiles, stream)                                            \
+        : launch_moe_skinny_x<XI_, false>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, \
+                                          out_stride, K, N, max_tiles, stream))
+  if (max_rows <= 4) DLI_MS(1);
+  else if (max_rows <= 8) DLI_MS(2);
+  else DLI_MS(4);
+#undef DLI_MS
 }
 
 }  // namespace dli

@@ -2,6 +2,7 @@
 // Every op launches on the *current* HIP stream, so the ops are capturable into hipGraphs
 // (torch.cuda.graph) without any host synchronisation (cdna guide §6 G9).
 #include <algorithm>
+#include <cstdlib>
 #include <ATen/ATen.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
@@ -190,6 +191,8 @@ void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
                              cur_stream(input));
 }
 
+const bool g_moe_no_skinny = std::getenv("DLI_NO_SKINNY_MOE") != nullptr;   // debugging / A-B measurements
+
 // ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
                  int64_t expert_offset) {
@@ -209,7 +212,28 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   const int64_t max_tiles = capacity / 128;
   Tensor ids = at::empty({n}, i32), wts = at::empty({n}, x.options().dtype(at::kFloat));
   Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
-  Tensor act = at::empty({capacity, I}, x.options()), out = at::empty({T, H}, x.options());
+  Tensor out = at::empty({T, H}, x.options());
+  if (T <= 16 && I % 128 == 0 && !g_moe_no_skinny) {
+    // Decode-sized batch: every expert sees ≤ 16 rows, so both projections are pure weight streams — the
+    // weight-streaming kernel of skinny_gemm.hip per (expert, 16 weight rows), SwiGLU in between.
+    const int64_t tiles = std::min<int64_t>(El, n);
+    Tensor gu = at::empty({tiles * 16, 2 * I}, x.options()), act16 = at::empty({tiles * 16, I}, x.options());
+    Tensor y16 = at::empty({n, H}, x.options());
+    dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
+    dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
+                          tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, stream);
+    dli::launch_moe_skinny(false, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
+                           meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, gu.data_ptr(), 2 * I, (int)H, (int)(2 * I),
+                           (int)tiles, (int)T, stream);
+    dli::launch_silu_and_mul(act16.data_ptr(), gu.data_ptr(), (int)(tiles * 16), (int)I, 2 * I, stream);
+    dli::launch_moe_skinny(true, act16.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
+                           meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y16.data_ptr(), H, (int)I, (int)H,
+                           (int)tiles, (int)T, stream);
+    dli::launch_moe_sum(y16.data_ptr(), false, 1, n * H, ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k, (int)T,
+                        (int)H, out.data_ptr(), stream);
+    return out;
+  }
+  Tensor act = at::empty({capacity, I}, x.options());
   // Down projection: with few row tiles (decode-sized batches) a (row tile × 128 columns) grid cannot fill 256 CUs and
   // every block would stream a 3.7 MB weight panel through a 16 KB-deep pipeline, so K is cut into slices whose fp32
   // partial slabs are summed (in fixed order) by moe_sum.  The slice count depends on T only: static under hipGraph.

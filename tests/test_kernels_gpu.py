@@ -244,6 +244,10 @@ def test_copy_pages():
 
 
 @pytest.mark.parametrize("T,H,I,E,El,off", [(1, 512, 1024, 4, 4, 0), (300, 4096, 1792, 8, 8, 0), (77, 1024, 448, 8, 2, 4),
+                                             # decode-sized: the weight-streaming path (T ≤ 16, I % 128 == 0)
+                                             (3, 4096, 1792, 8, 8, 0), (8, 1024, 14336, 8, 8, 0), (16, 4096, 1792, 8, 8, 0),
+                                             (16, 512, 256, 8, 2, 4), (5, 512, 256, 8, 1, 3), (16, 512, 256, 2, 2, 0),
+                                             (12, 512, 448, 8, 8, 0),          # I % 128 != 0 → grouped GEMM
                                              (1000, 512, 256, 8, 1, 3),
                                              (1500, 4096, 448, 8, 8, 0)])     # last: enough row tiles → no split-K
 def test_fused_moe_matches_reference(T, H, I, E, El, off):
