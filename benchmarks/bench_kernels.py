@@ -210,6 +210,10 @@ def bench_linear(quick):
                 return run
             t_lib = timeit(call(lambda a, w: F.linear(a, w)), iters=4 * copies, warmup=copies)
             t_sk = timeit(call(lambda a, w: ops.linear(a, w)), iters=4 * copies, warmup=copies)
+            if name == "gate_up":
+                t_f = timeit(call(lambda a, w: ops.linear_swiglu(a, w)), iters=4 * copies, warmup=copies)
+                t_u = timeit(call(lambda a, w: ops.silu_and_mul(ops.linear(a, w))), iters=4 * copies, warmup=copies)
+                report("linear_swiglu(gate_up)", t_f, bytes_=N * K * 2, M=M, N=N, K=K, unfused_us=round(t_u * 1e6, 2))
             report("linear(" + name + ")", t_sk, bytes_=N * K * 2, M=M, N=N, K=K, library_us=round(t_lib * 1e6, 2),
                    speedup=round(t_lib / t_sk, 2))
         del ws

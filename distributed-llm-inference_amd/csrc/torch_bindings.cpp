@@ -56,7 +56,7 @@ Tensor silu_and_mul(const Tensor& x) {
 }
 
 // y = x · Wᵀ (+ bias) for decode-sized x (≤ 16 rows): the weight-streaming kernel in kernels/skinny_gemm.hip
-Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias) {
+Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, bool swiglu) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   TORCH_CHECK(M >= 1 && M <= 16, "skinny_linear: 1..16 rows, got ", M);
@@ -69,8 +69,12 @@ Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tenso
     TORCH_CHECK(bias->is_cuda() && bias->scalar_type() == at::kBFloat16 && bias->is_contiguous() && bias->numel() == N);
     b = bias->data_ptr();
   }
-  Tensor out = at::empty({M, N}, x.options());
-  dli::launch_skinny_linear(out.data_ptr(), N, x.data_ptr(), x.stride(0), w.data_ptr(), b, (int)M, (int)N, (int)K, cur_stream(x));
+  // swiglu: w = [gate; up] (N = 2·I rows), result silu(x·gateᵀ) ⊙ (x·upᵀ) of width I
+  TORCH_CHECK(!swiglu || (N % 32 == 0 && b == nullptr), "skinny_linear: swiglu needs N % 32 == 0 and no bias");
+  const int64_t n_out = swiglu ? N / 2 : N;
+  Tensor out = at::empty({M, n_out}, x.options());
+  dli::launch_skinny_linear(out.data_ptr(), n_out, x.data_ptr(), x.stride(0), w.data_ptr(), b, (int)M, (int)N, (int)K, swiglu,
+                            cur_stream(x));
   return out;
 }
 
@@ -320,7 +324,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
-  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias) -> Tensor", &skinny_linear);
+  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False) -> Tensor", &skinny_linear);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
         "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale) -> ()", &rope_and_cache);
   m.def("copy_pages(Tensor(a!) cache, Tensor pairs) -> ()", &copy_pages);

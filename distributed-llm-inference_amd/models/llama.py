@@ -79,7 +79,7 @@ class SwiGLUMLP(nn.Module):
         self.down = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, ctx, dtype, device)
 
     def forward(self, h):
-        return self.down(ops.silu_and_mul(self.gate_up(h)))
+        return self.down(ops.linear_swiglu(h, self.gate_up.weight.data))
 
 
 class MoEBlock(nn.Module):

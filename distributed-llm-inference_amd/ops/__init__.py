@@ -126,6 +126,16 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return torch.nn.functional.linear(x, weight, bias)
 
 
+def linear_swiglu(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """``silu(x @ W_gateᵀ) * (x @ W_upᵀ)`` for a fused ``weight = [W_gate; W_up]``: one kernel at decode size
+    (SwiGLU in the epilogue of the weight-streaming GEMM), library GEMM + ``silu_and_mul`` otherwise."""
+    if (x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS and x.dtype == torch.bfloat16
+            and weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] % 128 == 0
+            and weight.shape[0] % 32 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+        return hip().skinny_linear(x, weight, None, True)
+    return silu_and_mul(torch.nn.functional.linear(x, weight))
+
+
 def rope_and_cache(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: Optional[torch.Tensor],
                    slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                    num_heads: int, num_kv_heads: int, head_dim: int,
