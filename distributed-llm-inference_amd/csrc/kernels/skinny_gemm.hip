@@ -134,7 +134,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint
   }
 }
 
-// MoE at decode size (T ≤ 16 tokens, so every expert sees ≤ 16 rows): one row tile per (weight row tile, expert
+// MoE at decode size (few tokens, so an expert sees ≤ 16 rows as a rule): one row tile per (weight row tile, expert
 // tile of moe_align).  DOWN = false: gate/up projection, activations gathered by token (sorted id / top_k), raw
 // result to gu[tile·16 + m][N] (the SwiGLU epilogue over 8 gate + 8 up rows per workgroup, as in the dense kernel,
 // measured 4–5 % SLOWER here: two distant 8-row streams per workgroup instead of one 16-row stream cost more than
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_
                                                                    const int* __restrict__ tile_expert,
                                                                    const int* __restrict__ meta,
                                                                    const float* __restrict__ topk_w, int top_k,
-                                                                   uint16_t* __restrict__ out, int64_t out_stride, int K) {
+                                                                   uint16_t* __restrict__ out, int64_t out_stride, int K,
+                                                                   int rows_pad) {
   extern __shared__ __attribute__((aligned(1024))) char sk_smem[];
   const int tile = blockIdx.y;
   if (tile >= meta[0]) return;
@@ -155,30 +156,36 @@ __global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_
   const int n0 = blockIdx.x * 16;
   const int* sids = sorted_ids + tile * MOE_BM;
   int M = 0;                                           // valid rows are packed at the front of the tile
-#pragma unroll
-  for (int i = 0; i < 16; ++i) M += sids[i] >= 0;
+  for (int i = 0; i < rows_pad; ++i) M += sids[i] >= 0;
   const uint16_t* we = w + (int64_t)tile_expert[tile] * w_expert_stride;
-  const char* xsrc[XI];
   const char* wsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = 4 * i + g, chunk = (r ^ row) << 4;
-    if (i < XI) {
-      const int rr = min(row, M - 1);
-      const int64_t arow = DOWN ? (int64_t)tile * 16 + rr : sids[rr] / top_k;
-      xsrc[i] = reinterpret_cast<const char*>(a + arow * a_stride) + chunk;
-    }
-    wsrc[i] = reinterpret_cast<const char*>(we + (int64_t)(n0 + row) * K) + chunk;
+    const int row = 4 * i + g;
+    wsrc[i] = reinterpret_cast<const char*>(we + (int64_t)(n0 + row) * K) + ((r ^ row) << 4);
   }
-  const float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
-  const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
-  if (m < M) {
-    if (DOWN) {
-      const int sid = sids[m];
-      out[(int64_t)sid * out_stride + n0 + nn] = f2bf(s * topk_w[sid]);
-    } else {
-      out[((int64_t)tile * 16 + m) * out_stride + n0 + nn] = f2bf(s);
+  // An expert with more than 16 rows (possible once T > 16) takes further passes over its 16 weight rows; the
+  // re-read comes from L2 / the infinity cache, and the batch sizes routed here keep that the exception.
+  for (int m0 = 0; m0 < M; m0 += 16) {
+    const int Ms = min(M - m0, 16);
+    const char* xsrc[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int row = 4 * i + g, rr = m0 + min(row, Ms - 1);
+      const int64_t arow = DOWN ? (int64_t)tile * rows_pad + rr : sids[rr] / top_k;
+      xsrc[i] = reinterpret_cast<const char*>(a + arow * a_stride) + ((r ^ row) << 4);
     }
+    const float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
+    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+    if (m < Ms) {
+      if (DOWN) {
+        const int sid = sids[m0 + m];
+        out[(int64_t)sid * out_stride + n0 + nn] = f2bf(s * topk_w[sid]);
+      } else {
+        out[((int64_t)tile * rows_pad + m0 + m) * out_stride + n0 + nn] = f2bf(s);
+      }
+    }
+    __syncthreads();                                   // the reduction scratch is the next pass's ring
   }
 }
 
@@ -204,22 +211,24 @@ void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t 
 template <int XI, bool DOWN>
 static void launch_moe_skinny_x(const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride, const int* sorted_ids,
                                 const int* tile_expert, const int* meta, const float* topk_w, int top_k, void* out,
-                                int64_t out_stride, int K, int N, int max_tiles, hipStream_t stream) {
+                                int64_t out_stride, int K, int N, int max_tiles, int rows_pad, hipStream_t stream) {
   constexpr int lds = SK_WAVES * 2 * (XI * 1024 + SK_TILE);
   hipLaunchKernelGGL((moe_skinny_kernel<XI, DOWN>), dim3(N / 16, max_tiles), dim3(SK_WAVES * 64), lds, stream,
                      (const uint16_t*)a, a_stride, (const uint16_t*)w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w,
-                     top_k, (uint16_t*)out, out_stride, K);
+                     top_k, (uint16_t*)out, out_stride, K, rows_pad);
 }
 
-// max_rows: upper bound of rows per expert (= T): picks how many activation rows a slab carries
+// max_rows: upper bound of rows per expert (= T ≤ 128): picks how many activation rows a slab carries; the
+// intermediate buffers hold rows_pad = ⌈max_rows / 16⌉·16 rows per expert tile.
 void launch_moe_skinny(bool down, const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride,
                        const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
                        void* out, int64_t out_stride, int K, int N, int max_tiles, int max_rows, hipStream_t stream) {
+  const int rows_pad = (max_rows + 15) / 16 * 16;
 #define DLI_MS(XI_)                                                                                                      \
   (down ? launch_moe_skinny_x<XI_, true>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, \
-                                         out_stride, K, N, max_tiles, stream)                                            \
+                                         out_stride, K, N, max_tiles, rows_pad, stream)                                  \
         : launch_moe_skinny_x<XI_, false>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, \
-                                          out_stride, K, N, max_tiles, stream))
+                                          out_stride, K, N, max_tiles, rows_pad, stream))
   if (max_rows <= 4) DLI_MS(1);
   else if (max_rows <= 8) DLI_MS(2);
   else DLI_MS(4);

@@ -195,7 +195,9 @@ void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
                              cur_stream(input));
 }
 
-const bool g_moe_no_skinny = std::getenv("DLI_NO_SKINNY_MOE") != nullptr;   // debugging / A-B measurements
+// largest batch routed to the weight-streaming MoE path; DLI_NO_SKINNY_MOE / DLI_SKINNY_MOE_MAX_T: A-B measurements
+const int64_t g_moe_skinny_max_t = std::getenv("DLI_NO_SKINNY_MOE") ? 0
+                                   : std::getenv("DLI_SKINNY_MOE_MAX_T") ? std::atoll(std::getenv("DLI_SKINNY_MOE_MAX_T")) : 32;
 
 // ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
@@ -217,11 +219,12 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   Tensor ids = at::empty({n}, i32), wts = at::empty({n}, x.options().dtype(at::kFloat));
   Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
   Tensor out = at::empty({T, H}, x.options());
-  if (T <= 16 && I % 128 == 0 && !g_moe_no_skinny) {
-    // Decode-sized batch: every expert sees ≤ 16 rows, so both projections are pure weight streams — the
+  if (T <= std::min<int64_t>(g_moe_skinny_max_t, 128) && I % 128 == 0) {
+    // Decode-sized batch: an expert sees ≤ 16 rows (at T ≤ 32 and 2-of-8 routing: nearly always; more rows cost an
+    // extra pass over that expert's weights from cache), so both projections are pure weight streams — the
     // weight-streaming kernel of skinny_gemm.hip per (expert, 16 weight rows), SwiGLU in between.
-    const int64_t tiles = std::min<int64_t>(El, n);
-    Tensor gu = at::empty({tiles * 16, 2 * I}, x.options()), act16 = at::empty({tiles * 16, I}, x.options());
+    const int64_t tiles = std::min<int64_t>(El, n), rows_pad = (T + 15) / 16 * 16;
+    Tensor gu = at::empty({tiles * rows_pad, 2 * I}, x.options()), act16 = at::empty({tiles * rows_pad, I}, x.options());
     Tensor y16 = at::empty({n, H}, x.options());
     dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
     dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
@@ -229,7 +232,7 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
     dli::launch_moe_skinny(false, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
                            meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, gu.data_ptr(), 2 * I, (int)H, (int)(2 * I),
                            (int)tiles, (int)T, stream);
-    dli::launch_silu_and_mul(act16.data_ptr(), gu.data_ptr(), (int)(tiles * 16), (int)I, 2 * I, stream);
+    dli::launch_silu_and_mul(act16.data_ptr(), gu.data_ptr(), (int)(tiles * rows_pad), (int)I, 2 * I, stream);
     dli::launch_moe_skinny(true, act16.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
                            meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y16.data_ptr(), H, (int)I, (int)H,
                            (int)tiles, (int)T, stream);

@@ -247,6 +247,8 @@ def test_copy_pages():
                                              # decode-sized: the weight-streaming path (T ≤ 16, I % 128 == 0)
                                              (3, 4096, 1792, 8, 8, 0), (8, 1024, 14336, 8, 8, 0), (16, 4096, 1792, 8, 8, 0),
                                              (16, 512, 256, 8, 2, 4), (5, 512, 256, 8, 1, 3), (16, 512, 256, 2, 2, 0),
+                                             (32, 512, 256, 2, 2, 0),          # 32 rows per expert: two passes each
+                                             (32, 4096, 1792, 8, 8, 0), (24, 512, 256, 8, 1, 3),
                                              (12, 512, 448, 8, 8, 0),          # I % 128 != 0 → grouped GEMM
                                              (1000, 512, 256, 8, 1, 3),
                                              (1500, 4096, 448, 8, 8, 0)])     # last: enough row tiles → no split-K
