@@ -196,6 +196,10 @@ def bench_linear(quick):
     Weights rotate through ≥ 1 GB of copies so that no call finds its matrix in the 256 MB infinity cache."""
     import torch.nn.functional as F
     shapes = [("qkv", 6144, 4096), ("o", 4096, 4096), ("gate_up", 28672, 4096), ("down", 4096, 14336), ("lm_head", 128256, 4096)]
+    if os.environ.get("DLI_BENCH_TP_SHAPES"):       # per-rank shards: Llama-3-70B at TP=8, Llama-3-8B at TP=4
+        shapes = [("70b_tp8_qkv", 1280, 8192), ("70b_tp8_o", 8192, 1024), ("70b_tp8_gate_up", 7168, 8192),
+                  ("70b_tp8_down", 8192, 3584), ("8b_tp4_qkv", 1536, 4096), ("8b_tp4_o", 4096, 1024),
+                  ("8b_tp4_gate_up", 7168, 4096), ("8b_tp4_down", 4096, 3584), ("70b_tp8_lm_head", 16032, 8192)]
     for name, N, K in (shapes[1:4] if quick else shapes):
         copies = max(2, -(-(1 << 30) // (N * K * 2)))
         ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(copies)]
@@ -210,7 +214,7 @@ def bench_linear(quick):
                 return run
             t_lib = timeit(call(lambda a, w: F.linear(a, w)), iters=4 * copies, warmup=copies)
             t_sk = timeit(call(lambda a, w: ops.linear(a, w)), iters=4 * copies, warmup=copies)
-            if name == "gate_up":
+            if name.endswith("gate_up"):
                 t_f = timeit(call(lambda a, w: ops.linear_swiglu(a, w)), iters=4 * copies, warmup=copies)
                 t_u = timeit(call(lambda a, w: ops.silu_and_mul(ops.linear(a, w))), iters=4 * copies, warmup=copies)
                 report("linear_swiglu(gate_up)", t_f, bytes_=N * K * 2, M=M, N=N, K=K, unfused_us=round(t_u * 1e6, 2))
