@@ -35,6 +35,30 @@ def timeit(fn, iters=20, warmup=3):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+def timeit_graph(fn, calls, replays=5):
+    """GPU time per call with the launches captured in one hipGraph (no host launch overhead in the number)."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(calls):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(replays):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / (replays * calls) * 1e-3
+
+
 def report(name, seconds, bytes_=None, flops=None, **kw):
     row = {"kernel": name, "us": round(seconds * 1e6, 2)}
     if bytes_:
@@ -203,7 +227,7 @@ def bench_linear(quick):
     for name, N, K in (shapes[1:4] if quick else shapes):
         copies = max(2, -(-(1 << 30) // (N * K * 2)))
         ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(copies)]
-        for M in ((1, 16) if quick else (1, 4, 8, 16)):
+        for M in ((1, 16) if quick else (24, 32, 48, 64) if os.environ.get("DLI_BENCH_MULTIPASS") else (1, 8, 16, 32) if os.environ.get("DLI_BENCH_GRAPH") else (1, 4, 8, 16)):
             x = torch.randn(M, K, device=DEV).bfloat16()
             state = {"i": 0}
 
@@ -212,8 +236,15 @@ def bench_linear(quick):
                     state["i"] = (state["i"] + 1) % copies
                     return fn(x, ws[state["i"]])
                 return run
+            if os.environ.get("DLI_BENCH_GRAPH"):       # both sides inside a hipGraph: pure GPU time
+                t_lib = timeit_graph(call(lambda a, w: F.linear(a, w)), 4 * copies)
+                t_sk = timeit_graph(call(lambda a, w: ops.hip().skinny_linear(a, w, None, False)), 4 * copies)
+                report("linear(" + name + ")", t_sk, bytes_=N * K * 2, M=M, N=N, K=K, library_us=round(t_lib * 1e6, 2),
+                       speedup=round(t_lib / t_sk, 2), timing="hipGraph")
+                continue
             t_lib = timeit(call(lambda a, w: F.linear(a, w)), iters=4 * copies, warmup=copies)
-            t_sk = timeit(call(lambda a, w: ops.linear(a, w)), iters=4 * copies, warmup=copies)
+            t_sk = timeit(call(lambda a, w: ops.hip().skinny_linear(a, w, None, False) if M > 16 else ops.linear(a, w)),
+                          iters=4 * copies, warmup=copies)
             if name.endswith("gate_up"):
                 t_f = timeit(call(lambda a, w: ops.linear_swiglu(a, w)), iters=4 * copies, warmup=copies)
                 t_u = timeit(call(lambda a, w: ops.silu_and_mul(ops.linear(a, w))), iters=4 * copies, warmup=copies)

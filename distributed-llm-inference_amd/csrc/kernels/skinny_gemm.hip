@@ -1,4 +1,4 @@
-// K10: decode-sized linear layer, y[M,N] = x[M,K] · W[N,K]ᵀ (+ bias) for M ≤ 16.
+// K10: decode-sized linear layer, y[M,N] = x[M,K] · W[N,K]ᵀ (+ bias) for M ≤ 16 (up to 64 in 16-token passes).
 //
 // At M ≤ 16 the layer is a pure stream of W through the chip (2·N·K bytes, ≈ 0 reuse), so the kernel is built
 // around HBM, not around the matrix cores: the product is computed transposed, yᵀ = W · xᵀ, with W as the MFMA
@@ -113,24 +113,35 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint
   const int n0 = blockIdx.x * (SWIGLU ? 8 : 16);
   // DMA sources: instruction i of a tile covers tile rows 4i + (lane>>4); this lane supplies LDS chunk p = lane&15,
   // i.e. global chunk p ^ row.  Rows ≥ M repeat the last token.
-  const char* xsrc[XI];
   const char* wsrc[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = 4 * i + g, chunk = (r ^ row) << 4;
-    if (i < XI) xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)min(row, M - 1) * x_stride) + chunk;
+    const int row = 4 * i + g;
     const int wrow = SWIGLU ? (row < 8 ? n0 + row : (N >> 1) + n0 + row - 8) : n0 + row;
-    wsrc[i] = reinterpret_cast<const char*>(w + (int64_t)wrow * K) + chunk;
+    wsrc[i] = reinterpret_cast<const char*>(w + (int64_t)wrow * K) + ((r ^ row) << 4);
   }
-  float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
-  const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
-  if (SWIGLU) {
-    const float up = __shfl_xor(s, 8, 64);             // thread nn < 8 holds gate column n0 + nn, thread nn + 8 its up
-    if (m < M && nn < 8)
-      out[(int64_t)m * out_stride + n0 + nn] = f2bf(s * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * s)) * up);
-  } else if (m < M) {
-    if (bias != nullptr) s += bf2f(bias[n0 + nn]);
-    out[(int64_t)m * out_stride + n0 + nn] = f2bf(s);
+  // More than 16 tokens: further passes over the same 16 weight rows, 16 tokens each.  The workgroup re-reads the
+  // 32–112 KiB it has just streamed; with K ≤ 1024-sized shards those re-reads hit L2 and the pass costs ≈ 40 % of
+  // the first, with K = 4096 they mostly miss and it costs as much — the caller decides by size (ops.linear).
+  for (int m0 = 0; m0 < M; m0 += 16) {
+    const int Ms = min(M - m0, 16);
+    const char* xsrc[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int row = 4 * i + g;
+      xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)(m0 + min(row, Ms - 1)) * x_stride) + ((r ^ row) << 4);
+    }
+    float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
+    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+    if (SWIGLU) {
+      const float up = __shfl_xor(s, 8, 64);           // thread nn < 8 holds gate column n0 + nn, thread nn + 8 its up
+      if (m < Ms && nn < 8)
+        out[(int64_t)(m0 + m) * out_stride + n0 + nn] = f2bf(s * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * s)) * up);
+    } else if (m < Ms) {
+      if (bias != nullptr) s += bf2f(bias[n0 + nn]);
+      out[(int64_t)(m0 + m) * out_stride + n0 + nn] = f2bf(s);
+    }
+    if (m0 + 16 < M) __syncthreads();                  // the reduction scratch is the next pass's ring
   }
 }
 

@@ -59,7 +59,7 @@ Tensor silu_and_mul(const Tensor& x) {
 Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, bool swiglu) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
-  TORCH_CHECK(M >= 1 && M <= 16, "skinny_linear: 1..16 rows, got ", M);
+  TORCH_CHECK(M >= 1 && M <= 64, "skinny_linear: 1..64 rows, got ", M);
   TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
               "skinny_linear: weight must be a contiguous bf16 [N, K] GPU tensor with K = ", K);
   TORCH_CHECK(K % 128 == 0 && N % 16 == 0 && reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0,

@@ -114,24 +114,35 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
 
 
 SKINNY_MAX_ROWS = 0 if os.environ.get("DLI_NO_SKINNY_GEMM") else 16
+SKINNY_MULTIPASS_BYTES = 32 << 20
+
+
+def _skinny_ok(x: torch.Tensor, weight: torch.Tensor, row_multiple: int) -> bool:
+    """Shapes the weight-streaming kernel takes, and batch sizes where it beats the library GEMM: up to 16 rows
+    always (one pass over W at 4–6 TB/s); up to 64 rows in 16-row passes while passes × weight bytes ≤ 32 MiB —
+    the small tensor-parallel shards, where re-reading 16 weight rows from L2 is cheaper than the library GEMM's
+    fixed cost (GPU time inside a hipGraph: ``profiles/skinny_linear_graph_timed_r1k.jsonl``)."""
+    m = x.shape[0] if x.dim() == 2 else 0
+    if not (x.is_cuda and 0 < m <= 4 * SKINNY_MAX_ROWS and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+        return False
+    if m > SKINNY_MAX_ROWS and (m + 15) // 16 * weight.numel() * 2 > SKINNY_MULTIPASS_BYTES:
+        return False
+    return (weight.is_contiguous() and weight.shape[1] % 128 == 0 and weight.shape[0] % row_multiple == 0
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``x @ weightᵀ + bias``.  Decode-sized GPU inputs (≤ 16 rows) take the weight-streaming MFMA kernel
+    """``x @ weightᵀ + bias``.  Decode-sized GPU inputs take the weight-streaming MFMA kernel
     (``csrc/kernels/skinny_gemm.hip``); everything else is a plain library GEMM (hipBLASLt through torch)."""
-    if (x.is_cuda and x.dim() == 2 and x.shape[0] <= SKINNY_MAX_ROWS and x.shape[0] > 0 and x.dtype == torch.bfloat16
-            and weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] % 128 == 0
-            and weight.shape[0] % 16 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
-        return hip().skinny_linear(x, weight, bias)
+    if _skinny_ok(x, weight, 16):
+        return hip().skinny_linear(x, weight, bias, False)
     return torch.nn.functional.linear(x, weight, bias)
 
 
 def linear_swiglu(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """``silu(x @ W_gateᵀ) * (x @ W_upᵀ)`` for a fused ``weight = [W_gate; W_up]``: one kernel at decode size
     (SwiGLU in the epilogue of the weight-streaming GEMM), library GEMM + ``silu_and_mul`` otherwise."""
-    if (x.is_cuda and x.dim() == 2 and 0 < x.shape[0] <= SKINNY_MAX_ROWS and x.dtype == torch.bfloat16
-            and weight.dtype == torch.bfloat16 and weight.is_contiguous() and weight.shape[1] % 128 == 0
-            and weight.shape[0] % 32 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+    if _skinny_ok(x, weight, 32):
         return hip().skinny_linear(x, weight, None, True)
     return silu_and_mul(torch.nn.functional.linear(x, weight))
 

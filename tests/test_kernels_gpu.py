@@ -284,11 +284,25 @@ def test_skinny_linear_matches_fp32_reference(M, N, K, bias):
     assert y.shape == (M, N) and y.dtype == torch.bfloat16
     err = (y.float() - want).abs().max().item()
     assert err <= 0.01 * want.abs().max().item() + 1e-3, err
-    # the dispatcher takes the kernel for these shapes and the library GEMM beyond 16 rows; both agree
+    # the dispatcher takes the kernel for these shapes; beyond 16 rows the kernel (small weights) or the library GEMM
     assert torch.equal(ops.linear(x, w, b), y)
     x17 = torch.randn(17, K, device="cuda").bfloat16()
     torch.testing.assert_close(ops.linear(x17, w, b).float(), x17.float() @ w.float().t() + (b.float() if bias else 0.0),
                                rtol=2e-2, atol=2e-2 * want.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K,swiglu", [(17, 4096, 1024, False), (40, 1280, 8192, False), (64, 256, 512, False),
+                                           (33, 512, 1024, True)])
+def test_skinny_linear_multi_pass(M, N, K, swiglu):
+    """More than 16 tokens: 16-token passes over the same weight rows."""
+    torch.manual_seed(M)
+    x = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    y = ops.hip().skinny_linear(x, w, None, swiglu).float()
+    want = x.float() @ w.float().t()
+    if swiglu:
+        want = torch.nn.functional.silu(want[:, :N // 2]) * want[:, N // 2:]
+    torch.testing.assert_close(y, want, rtol=2e-2, atol=2e-2 * want.abs().max().item())
 
 
 def test_skinny_linear_strided_rows_and_rejects_bad_shapes():
@@ -297,7 +311,7 @@ def test_skinny_linear_strided_rows_and_rejects_bad_shapes():
     w = (torch.randn(64, 512, device="cuda") * 0.05).bfloat16()
     torch.testing.assert_close(ops.hip().skinny_linear(x, w, None).float(), x.float() @ w.float().t(), rtol=2e-2, atol=2e-2)
     with pytest.raises(RuntimeError):
-        ops.hip().skinny_linear(torch.randn(17, 512, device="cuda").bfloat16(), w, None)
+        ops.hip().skinny_linear(torch.randn(65, 512, device="cuda").bfloat16(), w, None)
     with pytest.raises(RuntimeError):
         ops.hip().skinny_linear(torch.randn(2, 192, device="cuda").bfloat16(), (torch.randn(64, 192, device="cuda")).bfloat16(), None)
 
