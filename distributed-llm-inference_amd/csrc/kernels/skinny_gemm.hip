@@ -31,6 +31,12 @@ constexpr int MOE_BM = 128;      // rows per expert tile of moe_align (moe.hip: 
 // slot is XI KiB of activations followed by the 4 KiB weight tile.  (Two weight row tiles per workgroup — half the
 // activation traffic — measured 20–30 % SLOWER on every Llama shape: fewer, fatter workgroups per CU.)
 //
+// Swizzle of the activation tile: LDS chunk p of tile row t holds global chunk p ^ x_swz<XI>(t).  With all 16 rows
+// loaded it is the weight tile's p ^ t; with 8 or 4 rows (the other fragment columns alias them) the XOR is spread
+// so that the 16 (8) distinct addresses of a ds_read_b128 lane group still fall on different 16-byte slots.
+template <int XI>
+__device__ __forceinline__ int x_swz(int t) { return XI == 4 ? t : XI == 2 ? (t & 7) << 1 : (t & 3) << 2; }
+
 // The streaming loop + cross-wave reduction, shared by the dense and the MoE kernels.  xsrc[i] / wsrc[i]: this
 // lane's source of DMA instruction i (tile row 4i + (lane>>4), swizzled chunk already added) at k = 0.
 // Returns to thread t the sum for token m = t>>4 and weight row (t&15) of the tile.
@@ -60,7 +66,7 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     frag_off[j] = XI * 1024 + r * 256 + (((4 * j + g) ^ r) << 4);
-    xfrag_off[j] = xr * 256 + (((4 * j + g) ^ xr) << 4);
+    xfrag_off[j] = xr * 256 + (((4 * j + g) ^ x_swz<XI>(xr)) << 4);
   }
 
   if (wave < n_it) DLI_SK_ISSUE(wave, 0);
@@ -87,15 +93,17 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
 
   // lane holds yᵀ[n = 4g + j][m = r]; the ring is dead once every wave is past its loop
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);         // [wave][256]
+  // [wave][288]: element (j, lane) at 64j + lane + 4j + 2·(lane>>5): the 16 (j, g) runs of 16 tokens start on 16
+  // different even banks, so the transposed read below (32 lanes = 16 runs × 2 tokens) hits 32 different banks
+  float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) red[wave * 256 + j * 64 + lane] = acc[j];
+  for (int j = 0; j < 4; ++j) red[wave * 288 + j * 64 + lane + 4 * j + 2 * (lane >> 5)] = acc[j];
   __syncthreads();
   const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;     // consecutive threads → consecutive n of one token
-  const int src = (nn & 3) * 64 + (nn >> 2) * 16 + m;
+  const int src = (nn & 3) * 64 + (nn >> 2) * 16 + m + 4 * (nn & 3) + 2 * (nn >> 3);
   float s = 0.f;
 #pragma unroll
-  for (int wv_ = 0; wv_ < SK_WAVES; ++wv_) s += red[wv_ * 256 + src];
+  for (int wv_ = 0; wv_ < SK_WAVES; ++wv_) s += red[wv_ * 288 + src];
   return s;
 }
 
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int row = 4 * i + g;
-      xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)(m0 + min(row, Ms - 1)) * x_stride) + ((r ^ row) << 4);
+      xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)(m0 + min(row, Ms - 1)) * x_stride) + ((r ^ x_swz<XI>(row)) << 4);
     }
     float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_
     for (int i = 0; i < XI; ++i) {
       const int row = 4 * i + g, rr = m0 + min(row, Ms - 1);
       const int64_t arow = DOWN ? (int64_t)tile * rows_pad + rr : sids[rr] / top_k;
-      xsrc[i] = reinterpret_cast<const char*>(a + arow * a_stride) + ((r ^ row) << 4);
+      xsrc[i] = reinterpret_cast<const char*>(a + arow * a_stride) + ((r ^ x_swz<XI>(row)) << 4);
     }
     const float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
