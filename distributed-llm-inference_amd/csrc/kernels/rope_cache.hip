@@ -17,9 +17,10 @@ constexpr int D = 128;
 
 __device__ __forceinline__ int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
 
-constexpr int TB = 4;   // tokens per workgroup
-
-template <bool KV8>
+// TB = tokens per workgroup.  4 for prefill-sized launches (full 256-thread passes, grouped V stores); 1 for
+// decode-sized ones, where a launch is a handful of tokens and the kernel is pure latency: 4 tokens per workgroup
+// meant 5 dependent load → rotate → store rounds on 1–2 CUs (9 µs at T = 5), one token per workgroup needs 2.
+template <bool KV8, int TB>
 __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ qkv, int64_t row_stride,
                                                          const int* __restrict__ positions,
                                                          const float* __restrict__ cos_sin,  // [max_pos, D] or null
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
   // prefill chunk — whose TB tokens sit in consecutive cache slots — is written with one 8-byte store per (d row,
   // 4 tokens) instead of four 2-byte ones.  Decode tokens (one per sequence, unrelated slots) take the scalar path.
   const int s_first = slot_mapping[t0];
-  bool grouped = nt == TB && s_first >= 0 && (s_first & 3) == 0;
+  bool grouped = TB == 4 && nt == TB && s_first >= 0 && (s_first & 3) == 0;   // the 4-wide store needs 4 tokens
 #pragma unroll
   for (int i = 1; i < TB; ++i) grouped = grouped && (i >= nt || slot_mapping[t0 + i] == s_first + i);
   if (grouped) {
@@ -144,13 +145,18 @@ void launch_rope_and_cache(void* qkv, int64_t row_stride, const int* positions, 
                            const int* slot_mapping, void* k_cache, void* v_cache, int T, int Hq, int Hkv,
                            bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
   if (T == 0) return;
-  const dim3 grid((T + TB - 1) / TB);
-  if (kv_fp8)
-    hipLaunchKernelGGL(rope_cache_kernel<true>, grid, dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
-                       cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, 1.f / k_scale, 1.f / v_scale);
-  else
-    hipLaunchKernelGGL(rope_cache_kernel<false>, grid, dim3(256), 0, stream, (uint16_t*)qkv, row_stride, positions,
-                       cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, 1.f, 1.f);
+#define DLI_ROPE(KV8_, TB_, ks_, vs_)                                                                                   \
+  hipLaunchKernelGGL((rope_cache_kernel<KV8_, TB_>), dim3((T + TB_ - 1) / TB_), dim3(256), 0, stream, (uint16_t*)qkv,   \
+                     row_stride, positions, cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, ks_, vs_)
+  const bool small = T <= 128;                          // ≤ 128 workgroups either way: take the short dependency chain
+  if (kv_fp8) {
+    if (small) DLI_ROPE(true, 1, 1.f / k_scale, 1.f / v_scale);
+    else DLI_ROPE(true, 4, 1.f / k_scale, 1.f / v_scale);
+  } else {
+    if (small) DLI_ROPE(false, 1, 1.f, 1.f);
+    else DLI_ROPE(false, 4, 1.f, 1.f);
+  }
+#undef DLI_ROPE
 }
 
 // K9 helper: device-side page copy for copy-on-write (pairs = [n, 2] int32: src, dst page ids).
