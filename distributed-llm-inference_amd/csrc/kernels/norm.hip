@@ -24,12 +24,14 @@ __global__ __launch_bounds__(NT) void rms_norm_kernel(uint16_t* out, const uint1
   const int nvec = H >> 3;
 
   float vals[MAXV][8];
+  bf16x8 gw[MAXV];          // weights are fetched with the row, not after the reduction: one memory latency, not two
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * NT;
     if (v < nvec) {
       bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + v * 8);
+      gw[i] = *reinterpret_cast<const bf16x8*>(w + v * 8);
       if (ADD_RESIDUAL) {
         bf16x8 r = *reinterpret_cast<const bf16x8*>(rr + v * 8);
         bf16x8 s;
@@ -72,10 +74,9 @@ __global__ __launch_bounds__(NT) void rms_norm_kernel(uint16_t* out, const uint1
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * NT;
     if (v < nvec) {
-      bf16x8 g = *reinterpret_cast<const bf16x8*>(w + v * 8);
       bf16x8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(vals[i][j] * inv * bf2f((uint16_t)g[j]));
+      for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(vals[i][j] * inv * bf2f((uint16_t)gw[i][j]));
       *reinterpret_cast<bf16x8*>(orow + v * 8) = o;
     }
   }
