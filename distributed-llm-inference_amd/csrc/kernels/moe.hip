@@ -104,9 +104,8 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
     const float* __restrict__ topk_w, int top_k, void* __restrict__ out_, int64_t out_stride, int K, int N_half,
     int n_col_blocks, int k_splits, int64_t slab_elems) {
   uint16_t* out = reinterpret_cast<uint16_t*>(out_);
-  __shared__ __attribute__((aligned(16))) char lds[2 * BM * BK * 2];
-  char* ldsA = lds;
-  char* ldsB = lds + BM * BK * 2;
+  constexpr int STAGE = 2 * BM * BK * 2;                     // A tile + B tile of one K-step
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];   // double-buffered, filled by LDS-DMA
   // ---- block → (row tile, column block), XCD-aware.  The hardware deals workgroups round-robin over the 8
   // XCDs (id % 8), each with a private 4 MB L2.  Work is cut into super-tiles of 8 row tiles × 8 column
   // blocks; XCD k runs super-tiles k, k+8, …, 64 consecutive workgroups each, so the blocks resident on
@@ -135,14 +134,15 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int col = lane & 15, g = lane >> 4;
 
-  // ---- staging assignment: thread owns chunks q = tid + 256 i (i < 4): row q/8, chunk q%8, for A and B
+  // ---- staging: LDS-DMA (global_load_lds, 16 bytes per lane, no VGPRs, no ds_write).  DMA instruction i of wave w
+  // fills the 1 KiB at (w + 4i)·1024 of a tile in lane order, i.e. lane → LDS chunk q = tid + 256 i: row q/8,
+  // slot q%8.  The bank swizzle of lds_off is applied on the source side: slot p of row r receives global chunk
+  // p ^ (r & 7).
   const uint16_t* a_src[4];
   const uint16_t* b_src[4];
-  int st_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int q = tid + 256 * i, r = q >> 3, c = q & 7;
-    st_off[i] = lds_off(r, c);
+    const int q = tid + 256 * i, r = q >> 3, c = (q & 7) ^ (r & 7);
     int64_t arow;
     if (EPI == EPI_SWIGLU) {
       const int sid = sorted_ids[tile * BM + r];
@@ -171,27 +171,24 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
   const int nk_total = K / BK;
   const int kt0 = (int)((int64_t)nk_total * split / k_splits);
   const int nk = (int)((int64_t)nk_total * (split + 1) / k_splits);
-  bf16x8 pa[4], pb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    pa[i] = *reinterpret_cast<const bf16x8*>(a_src[i] + kt0 * BK);
-    pb[i] = *reinterpret_cast<const bf16x8*>(b_src[i] + kt0 * BK);
+  using gptr_t = const __attribute__((address_space(1))) void*;
+  using lptr_t = __attribute__((address_space(3))) void*;
+#define DLI_GG_STAGE(kt_, buf_)                                                                                   \
+  {                                                                                                               \
+    char* dst_ = lds + (buf_) * STAGE + wave * 1024;                  /* wave-uniform; + lane·16 by hardware */   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + (kt_) * BK), (lptr_t)(dst_ + i * 4096), 16, 0, 0);     \
+      __builtin_amdgcn_global_load_lds((gptr_t)(b_src[i] + (kt_) * BK), (lptr_t)(dst_ + BM * BK * 2 + i * 4096), 16, 0, 0); \
+    }                                                                                                             \
   }
+  DLI_GG_STAGE(kt0, 0);
   for (int kt = kt0; kt < nk; ++kt) {
-    __syncthreads();                                           // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<bf16x8*>(ldsA + st_off[i]) = pa[i];
-      *reinterpret_cast<bf16x8*>(ldsB + st_off[i]) = pb[i];
-    }
-    __syncthreads();
-    if (kt + 1 < nk) {                                         // prefetch the next K tile under the MFMAs
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        pa[i] = *reinterpret_cast<const bf16x8*>(a_src[i] + (kt + 1) * BK);
-        pb[i] = *reinterpret_cast<const bf16x8*>(b_src[i] + (kt + 1) * BK);
-      }
-    }
+    const int buf = (kt - kt0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my share of K-step kt has landed …
+    __syncthreads();                                           // … everyone's has, and everyone is done with kt-1
+    if (kt + 1 < nk) DLI_GG_STAGE(kt + 1, buf ^ 1);            // next K-step streams in under the MFMAs
+    const char* ldsA = lds + buf * STAGE;
+    const char* ldsB = ldsA + BM * BK * 2;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[4], fb[4];
@@ -207,6 +204,8 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
       // lane holds 4 *consecutive output columns* of one token row → 8-byte row-contiguous stores
     }
   }
+
+#undef DLI_GG_STAGE
 
   // ---- epilogue.  acc[m][n][r]: token row = wm*64 + m*16 + col, output column = wn*64 + n*16 + 4g + r
 #pragma unroll
