@@ -12,8 +12,10 @@
 // reads the MFMA fragments back with ds_read_b128.  One DMA instruction fills 1 KiB of LDS in lane order, so the
 // bank swizzle is applied on the source side: LDS chunk p of tile row t holds global 16-byte chunk p ^ t; the
 // fragment read of chunk c = 4j + (l>>4) of row t = l&15 goes to slot c ^ t, which is conflict-free for the
-// 16-lane groups of ds_read_b128.  The activations take the same path as a 17th "row tile" (rows ≥ M repeat the
-// last token; those output columns are never stored), so every tile of the ring has the same shape.
+// 16-lane groups of ds_read_b128.  The activations take the same path (rows ≥ M repeat the last token; those output
+// columns are never stored); with M ≤ 4 / ≤ 8 only 4 / 8 token rows are fetched per slab and the remaining fragment
+// columns alias them (x_swz below keeps those reads conflict-free too: SQ_LDS_BANK_CONFLICT = 0,
+// profiles/pmc_skinny_r1k.md).
 //
 // A 256-thread workgroup owns 16 weight rows; its 4 waves split K between them in interleaved 128-element
 // slabs, each wave double-buffers its slabs in a private LDS ring (no barriers in the loop: the wave waits on its
