@@ -20,12 +20,15 @@
 // A 256-thread workgroup owns 16 weight rows; its 4 waves split K between them in interleaved 128-element
 // slabs, each wave double-buffers its slabs in a private LDS ring (no barriers in the loop: the wave waits on its
 // own vmcnt), the 4 partial accumulators meet in LDS at the end and the sum is written as bf16.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace dli {
 
 constexpr int SK_WAVES = 4;
+static const bool g_skinny_no_8w = std::getenv("DLI_SKINNY_NO_8W") != nullptr;   // A-B measurements
 constexpr int SK_TILE = 4096;    // bytes: 16 rows × 128 bf16
 constexpr int MOE_BM = 128;      // rows per expert tile of moe_align (moe.hip: BM)
 
@@ -42,7 +45,7 @@ __device__ __forceinline__ int x_swz(int t) { return XI == 4 ? t : XI == 2 ? (t 
 // The streaming loop + cross-wave reduction, shared by the dense and the MoE kernels.  xsrc[i] / wsrc[i]: this
 // lane's source of DMA instruction i (tile row 4i + (lane>>4), swizzled chunk already added) at k = 0.
 // Returns to thread t the sum for token m = t>>4 and weight row (t&15) of the tile.
-template <int XI>
+template <int XI, int NW = SK_WAVES>
 __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const char* const (&wsrc)[4], int K, char* smem) {
   constexpr int SLOT = XI * 1024 + SK_TILE;           // bytes per slab: activations + weight tile
   constexpr int XROWS = 4 * XI;
@@ -73,10 +76,10 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
 
   if (wave < n_it) DLI_SK_ISSUE(wave, 0);
   int slot = 0;
-  for (int it = wave; it < n_it; it += SK_WAVES, slot ^= 1) {
+  for (int it = wave; it < n_it; it += NW, slot ^= 1) {
     // the other slot was consumed by the MFMAs of the previous iteration (they waited for its ds_reads)
-    if (it + SK_WAVES < n_it) {
-      DLI_SK_ISSUE(it + SK_WAVES, slot ^ 1);
+    if (it + NW < n_it) {
+      DLI_SK_ISSUE(it + NW, slot ^ 1);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + 4) : "memory");     // everything but the slab just issued
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -105,15 +108,15 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
   const int src = (nn & 3) * 64 + (nn >> 2) * 16 + m + 4 * (nn & 3) + 2 * (nn >> 3);
   float s = 0.f;
 #pragma unroll
-  for (int wv_ = 0; wv_ < SK_WAVES; ++wv_) s += red[wv_ * 288 + src];
+  for (int wv_ = 0; wv_ < NW; ++wv_) s += red[wv_ * 288 + src];
   return s;
 }
 
 // SWIGLU: W is a fused [gate; up] projection (N = 2·I rows).  A workgroup then takes 8 gate rows and the 8 matching
 // up rows as its 16-row tile and stores silu(gate)·up — [M, I] — so the activation kernel and the round trip of the
 // [M, 2·I] intermediate disappear from the decode step.
-template <int XI, bool SWIGLU>
-__global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
+template <int XI, bool SWIGLU, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
                                                                       const uint16_t* __restrict__ w,
                                                                       const uint16_t* __restrict__ bias,
                                                                       uint16_t* __restrict__ out, int64_t out_stride,
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_linear_kernel(const uint
       const int row = 4 * i + g;
       xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)(m0 + min(row, Ms - 1)) * x_stride) + ((r ^ x_swz<XI>(row)) << 4);
     }
-    float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
-    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
+    float s = skinny_dot<XI, NW>(xsrc, wsrc, K, sk_smem);
+    const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;   // m ≥ 16 (waves 4–7 of the 8-wave form): nothing to store
     if (SWIGLU) {
       const float up = __shfl_xor(s, 8, 64);           // thread nn < 8 holds gate column n0 + nn, thread nn + 8 its up
       if (m < Ms && nn < 8)
@@ -210,19 +213,32 @@ __global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_
   }
 }
 
-template <int XI, bool SWIGLU>
+// NW = waves per workgroup = in-workgroup K split.  Layers with few weight-row tiles (o / down / qkv, tensor-parallel
+// shards) are latency chains — slabs per wave × HBM round trip — so they take 8 waves: half the slabs per wave, twice
+// the bytes in flight per workgroup, 80–128 KiB of LDS.  Measured in a hipGraph: −4…−14 % up to 256 workgroups (one
+// per CU either way) and up to 512 with M ≤ 4 (80 KiB: still two per CU); beyond that the lost occupancy costs more.
+template <int XI, bool SWIGLU, int NW>
 static void launch_skinny(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, hipStream_t stream) {
-  constexpr int lds = SK_WAVES * 2 * (XI * 1024 + SK_TILE);        // 40 / 48 / 64 KiB: 2–4 workgroups per CU
-  hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU>), dim3(N / 16), dim3(SK_WAVES * 64), lds, stream, (const uint16_t*)x,
+  constexpr int lds = NW * 2 * (XI * 1024 + SK_TILE);
+  static bool configured = false;                      // > 64 KiB of dynamic LDS needs the opt-in, once per process
+  if (lds > 65536 && !configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, SWIGLU, NW>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    configured = true;
+  }
+  hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU, NW>), dim3(N / 16), dim3(NW * 64), lds, stream, (const uint16_t*)x,
                      x_stride, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, out_stride, M, N, K);
 }
 
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, bool swiglu, hipStream_t stream) {
+  const int tiles = N / 16;
+  const bool narrow = (tiles <= 256 || (tiles <= 512 && M <= 4)) && K >= 1024 && !g_skinny_no_8w;
 #define DLI_SK(XI_)                                                                                   \
-  (swiglu ? launch_skinny<XI_, true>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)          \
-          : launch_skinny<XI_, false>(out, out_stride, x, x_stride, w, bias, M, N, K, stream))
+  (swiglu   ? launch_skinny<XI_, true, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)     \
+   : narrow ? launch_skinny<XI_, false, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)    \
+            : launch_skinny<XI_, false, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream))
   if (M <= 4) DLI_SK(1);
   else if (M <= 8) DLI_SK(2);
   else DLI_SK(4);
