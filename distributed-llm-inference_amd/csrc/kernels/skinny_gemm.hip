@@ -221,18 +221,22 @@ template <int XI, bool SWIGLU, int NW>
 static void launch_skinny(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, hipStream_t stream) {
   constexpr int lds = NW * 2 * (XI * 1024 + SK_TILE);
-  static bool configured = false;                      // > 64 KiB of dynamic LDS needs the opt-in, once per process
-  if (lds > 65536 && !configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, SWIGLU, NW>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    configured = true;
-  }
   hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU, NW>), dim3(N / 16), dim3(NW * 64), lds, stream, (const uint16_t*)x,
                      x_stride, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, out_stride, M, N, K);
 }
 
+template <int XI>
+static void allow_big_lds() {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, false, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * (XI * 1024 + SK_TILE));
+}
+
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, bool swiglu, hipStream_t stream) {
+  // > 64 KiB of dynamic LDS needs an opt-in per kernel; done for every 8-wave variant on the first call, so that no
+  // attribute call can fall inside a later stream capture
+  static const bool configured = [] { allow_big_lds<1>(); allow_big_lds<2>(); allow_big_lds<4>(); return true; }();
+  (void)configured;
   const int tiles = N / 16;
   const bool narrow = (tiles <= 256 || (tiles <= 512 && M <= 4)) && K >= 1024 && !g_skinny_no_8w;
 #define DLI_SK(XI_)                                                                                   \
