@@ -229,6 +229,8 @@ template <int XI>
 static void allow_big_lds() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, false, 8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * (XI * 1024 + SK_TILE));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, true, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * (XI * 1024 + SK_TILE));
 }
 
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
@@ -240,9 +242,10 @@ void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t 
   const int tiles = N / 16;
   const bool narrow = (tiles <= 256 || (tiles <= 512 && M <= 4)) && K >= 1024 && !g_skinny_no_8w;
 #define DLI_SK(XI_)                                                                                   \
-  (swiglu   ? launch_skinny<XI_, true, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)     \
-   : narrow ? launch_skinny<XI_, false, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)    \
-            : launch_skinny<XI_, false, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream))
+  (swiglu ? (narrow ? launch_skinny<XI_, true, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)    \
+                    : launch_skinny<XI_, true, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream))   \
+          : (narrow ? launch_skinny<XI_, false, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)   \
+                    : launch_skinny<XI_, false, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)))
   if (M <= 4) DLI_SK(1);
   else if (M <= 8) DLI_SK(2);
   else DLI_SK(4);
