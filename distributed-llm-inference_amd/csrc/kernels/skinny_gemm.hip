@@ -213,10 +213,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_
   }
 }
 
-// NW = waves per workgroup = in-workgroup K split.  Layers with few weight-row tiles (o / down / qkv, tensor-parallel
-// shards) are latency chains — slabs per wave × HBM round trip — so they take 8 waves: half the slabs per wave, twice
-// the bytes in flight per workgroup, 80–128 KiB of LDS.  Measured in a hipGraph: −4…−14 % up to 256 workgroups (one
-// per CU either way) and up to 512 with M ≤ 4 (80 KiB: still two per CU); beyond that the lost occupancy costs more.
+// NW = waves per workgroup = in-workgroup K split.  A workgroup is a latency chain — slabs per wave × HBM round trip —
+// so 8 waves (half the slabs per wave, twice the bytes in flight per workgroup, 80–128 KiB of LDS) win wherever they
+// do not cost occupancy.  Measured in a hipGraph: −4…−14 % up to 256 workgroups (one per CU either way) at any M, and
+// −4…−6 % on every shape at M ≤ 4 (80 KiB: still two workgroups per CU; gate/up 6.0, LM head 6.3 TB/s); with M > 4
+// and more workgroups than CUs the lost occupancy costs more than the shorter chain gains.
 template <int XI, bool SWIGLU, int NW>
 static void launch_skinny(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, hipStream_t stream) {
@@ -240,7 +241,7 @@ void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t 
   static const bool configured = [] { allow_big_lds<1>(); allow_big_lds<2>(); allow_big_lds<4>(); return true; }();
   (void)configured;
   const int tiles = N / 16;
-  const bool narrow = (tiles <= 256 || (tiles <= 512 && M <= 4)) && K >= 1024 && !g_skinny_no_8w;
+  const bool narrow = (tiles <= 256 || M <= 4) && K >= 1024 && !g_skinny_no_8w;
 #define DLI_SK(XI_)                                                                                   \
   (swiglu ? (narrow ? launch_skinny<XI_, true, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)    \
                     : launch_skinny<XI_, true, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream))   \
