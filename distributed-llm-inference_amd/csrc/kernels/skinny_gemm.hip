@@ -164,8 +164,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* 
 // measured 4–5 % SLOWER here: two distant 8-row streams per workgroup instead of one 16-row stream cost more than
 // the separate activation kernel).  DOWN = true: activations act[tile·16 + m][K], result scaled by the routing
 // weight and stored at its (token, slot) row y[sorted id][N] for moe_sum.
-template <int XI, bool DOWN>
-__global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_t* __restrict__ a, int64_t a_stride,
+template <int XI, bool DOWN, int NW>
+__global__ __launch_bounds__(NW * 64) void moe_skinny_kernel(const uint16_t* __restrict__ a, int64_t a_stride,
                                                                    const uint16_t* __restrict__ w, int64_t w_expert_stride,
                                                                    const int* __restrict__ sorted_ids,
                                                                    const int* __restrict__ tile_expert,
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void moe_skinny_kernel(const uint16_
       const int64_t arow = DOWN ? (int64_t)tile * rows_pad + rr : sids[rr] / top_k;
       xsrc[i] = reinterpret_cast<const char*>(a + arow * a_stride) + ((r ^ x_swz<XI>(row)) << 4);
     }
-    const float s = skinny_dot<XI>(xsrc, wsrc, K, sk_smem);
+    const float s = skinny_dot<XI, NW>(xsrc, wsrc, K, sk_smem);
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;
     if (m < Ms) {
       if (DOWN) {
@@ -253,12 +253,19 @@ void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t 
 #undef DLI_SK
 }
 
-template <int XI, bool DOWN>
+template <int XI, bool DOWN, int NW>
 static void launch_moe_skinny_x(const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride, const int* sorted_ids,
                                 const int* tile_expert, const int* meta, const float* topk_w, int top_k, void* out,
                                 int64_t out_stride, int K, int N, int max_tiles, int rows_pad, hipStream_t stream) {
-  constexpr int lds = SK_WAVES * 2 * (XI * 1024 + SK_TILE);
-  hipLaunchKernelGGL((moe_skinny_kernel<XI, DOWN>), dim3(N / 16, max_tiles), dim3(SK_WAVES * 64), lds, stream,
+  constexpr int lds = NW * 2 * (XI * 1024 + SK_TILE);
+  static const bool configured = [] {                  // 8 waves: 80 KiB of dynamic LDS needs the opt-in
+    if (lds > 65536)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_skinny_kernel<XI, DOWN, NW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return true;
+  }();
+  (void)configured;
+  hipLaunchKernelGGL((moe_skinny_kernel<XI, DOWN, NW>), dim3(N / 16, max_tiles), dim3(NW * 64), lds, stream,
                      (const uint16_t*)a, a_stride, (const uint16_t*)w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w,
                      top_k, (uint16_t*)out, out_stride, K, rows_pad);
 }
@@ -269,14 +276,14 @@ void launch_moe_skinny(bool down, const void* a, int64_t a_stride, const void* w
                        const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
                        void* out, int64_t out_stride, int K, int N, int max_tiles, int max_rows, hipStream_t stream) {
   const int rows_pad = (max_rows + 15) / 16 * 16;
-#define DLI_MS(XI_)                                                                                                      \
-  (down ? launch_moe_skinny_x<XI_, true>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, \
-                                         out_stride, K, N, max_tiles, rows_pad, stream)                                  \
-        : launch_moe_skinny_x<XI_, false>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, \
-                                          out_stride, K, N, max_tiles, rows_pad, stream))
-  if (max_rows <= 4) DLI_MS(1);
-  else if (max_rows <= 8) DLI_MS(2);
-  else DLI_MS(4);
+#define DLI_MS(XI_, NW_)                                                                                                 \
+  (down ? launch_moe_skinny_x<XI_, true, NW_>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, \
+                                              out, out_stride, K, N, max_tiles, rows_pad, stream)                        \
+        : launch_moe_skinny_x<XI_, false, NW_>(a, a_stride, w, w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, \
+                                               out, out_stride, K, N, max_tiles, rows_pad, stream))
+  if (max_rows <= 4) DLI_MS(1, 8);                     // as in the dense kernel: 8 waves pay while two workgroups fit a CU
+  else if (max_rows <= 8) DLI_MS(2, 4);
+  else DLI_MS(4, 4);
 #undef DLI_MS
 }
 
