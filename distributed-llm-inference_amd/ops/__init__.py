@@ -117,17 +117,20 @@ SKINNY_MAX_ROWS = 0 if os.environ.get("DLI_NO_SKINNY_GEMM") else 16
 SKINNY_MULTIPASS_BYTES = 32 << 20
 
 
+def skinny_rows_ok(m: int, n: int, k: int, row_multiple: int = 16) -> bool:
+    """Batch sizes and shapes for which the weight-streaming kernel beats the library GEMM: up to 16 rows always
+    (one pass over W at 4–6 TB/s); up to 64 rows in 16-row passes while passes × weight bytes ≤ 32 MiB — the small
+    tensor-parallel shards, where re-reading 16 weight rows from L2 is cheaper than the library GEMM's fixed cost
+    (GPU time inside a hipGraph: ``profiles/skinny_linear_graph_timed_r1n.jsonl``)."""
+    if not (0 < m <= 4 * SKINNY_MAX_ROWS and k % 128 == 0 and n % row_multiple == 0):
+        return False
+    return m <= SKINNY_MAX_ROWS or (m + 15) // 16 * n * k * 2 <= SKINNY_MULTIPASS_BYTES
+
+
 def _skinny_ok(x: torch.Tensor, weight: torch.Tensor, row_multiple: int) -> bool:
-    """Shapes the weight-streaming kernel takes, and batch sizes where it beats the library GEMM: up to 16 rows
-    always (one pass over W at 4–6 TB/s); up to 64 rows in 16-row passes while passes × weight bytes ≤ 32 MiB —
-    the small tensor-parallel shards, where re-reading 16 weight rows from L2 is cheaper than the library GEMM's
-    fixed cost (GPU time inside a hipGraph: ``profiles/skinny_linear_graph_timed_r1k.jsonl``)."""
-    m = x.shape[0] if x.dim() == 2 else 0
-    if not (x.is_cuda and 0 < m <= 4 * SKINNY_MAX_ROWS and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16):
         return False
-    if m > SKINNY_MAX_ROWS and (m + 15) // 16 * weight.numel() * 2 > SKINNY_MULTIPASS_BYTES:
-        return False
-    return (weight.is_contiguous() and weight.shape[1] % 128 == 0 and weight.shape[0] % row_multiple == 0
+    return (skinny_rows_ok(x.shape[0], weight.shape[0], weight.shape[1], row_multiple) and weight.is_contiguous()
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
 

@@ -295,3 +295,20 @@ def test_slo_aware_admission_serves_requests_that_can_still_make_their_deadline_
     while eng2.has_unfinished():
         order2 += [o.req_id for o in eng2.step() if o.finished]
     assert order2 == ["late", "fresh"]
+
+
+def test_decode_sized_gemm_dispatch_rule():
+    """ops.linear: which (rows, N, K) go to the weight-streaming kernel (csrc/kernels/skinny_gemm.hip)."""
+    from dli_amd import ops
+    ok = ops.skinny_rows_ok
+    assert ok(1, 4096, 4096) and ok(16, 28672, 4096) and ok(16, 128256, 4096)       # ≤ 16 rows: always
+    assert not ok(17, 4096, 4096) and not ok(32, 6144, 4096)                         # 32 MB+ matrices: library above 16
+    assert ok(32, 8192, 1024) and ok(64, 4096, 1024) and ok(32, 1536, 4096)          # small TP shards: 16-row passes
+    assert not ok(64, 8192, 1024) and not ok(65, 1024, 1024) and not ok(0, 4096, 4096)
+    assert not ok(4, 4096, 4000) and not ok(4, 4100, 4096)                           # K % 128, N % 16
+    assert ok(4, 28672, 4096, 32) and not ok(4, 28688, 4096, 32)                     # fused gate/up: N % 32
+    x = torch.randn(4, 256).bfloat16()
+    w = torch.randn(64, 256).bfloat16()
+    torch.testing.assert_close(ops.linear(x, w), torch.nn.functional.linear(x, w))   # CPU tensors: library path
+    want = torch.nn.functional.silu(x.float() @ w[:32].float().t()) * (x.float() @ w[32:].float().t())
+    torch.testing.assert_close(ops.linear_swiglu(x, w).float(), want, rtol=2e-2, atol=2e-2)
