@@ -120,6 +120,14 @@ class SchedulerConfig:
     # Under overload FCFS makes EVERY request late (the queue only grows); this keeps goodput at capacity.
     ttft_slo: Optional[float] = None
     ttft_slo_margin: float = 0.3            # fraction of ttft_slo kept for the prefill itself (queueing budget = the rest)
+    # Bounded deferral / overload shedding: a request that has waited this long without being admitted is finished
+    # with reason "shed" (its client gets an error line instead of hanging for ever); None keeps every request.
+    max_queue_delay: Optional[float] = None
+    # TPOT-targeting token budget: when set, the share of a step given to prefill shrinks (and admission pauses)
+    # while the measured step time would push running decodes past this many seconds per output token.
+    tpot_slo: Optional[float] = None
+    tpot_slo_margin: float = 0.85           # aim the step time at this fraction of tpot_slo
+    min_prefill_tokens: int = 128           # the prefill share never shrinks below this while decodes meet the target
 
 
 @dataclass
@@ -129,6 +137,9 @@ class ParallelConfig:
     ep: int = 1                             # expert-parallel degree (MoE); ep ≤ tp, experts sharded over tp group
     custom_all_reduce: bool = True
     backend: str = "auto"                   # "auto" → nccl(=RCCL) on GPU, gloo on CPU
+    # expert parallelism: steps of at least this many tokens dispatch (token, expert) rows by all-to-all instead of
+    # evaluating the local experts on replicated activations + all-reduce (0: always replicated)
+    ep_a2a_min_tokens: int = 2048
 
 
 @dataclass

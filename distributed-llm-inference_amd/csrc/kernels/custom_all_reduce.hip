@@ -1,12 +1,18 @@
-// K7: all-reduce over IPC-mapped peer buffers for the fully connected xGMI mesh.
+// K7: all-reduce / all-gather / broadcast over IPC-mapped peer buffers for the fully connected xGMI mesh
+// (SURVEY.md §2.5, §5.8).
 //
 // MI355X nodes wire every GPU to every other GPU with a private xGMI link, so ring algorithms (one
 // link busy per GPU, 2(N-1) hops) are the wrong shape for the decode-sized messages of tensor
-// parallelism.  Both kernels here are *direct*:
+// parallelism.  The kernels here are *direct*:
 //
 //   one-shot  (small):  every rank reads all N staging buffers and reduces locally     — 1 hop
 //   two-shot  (larger): rank r reduces slice r from its N-1 peers (all links in use at once), then
 //                       every rank gathers the N reduced slices                         — 2 hops
+//
+// The world size is a template parameter (2, 4, 8; anything else takes the generic instance): the
+// per-element loop issues the loads from ALL peers before the first add, so a thread keeps
+// world × 16 bytes in flight over world-1 different links instead of walking the peers one
+// round-trip at a time.
 //
 // Protocol per call (all inside one launch, so the op is hipGraph-capturable; the per-block epoch
 // counter lives in device memory and advances by itself on every replay):
@@ -15,10 +21,17 @@
 //   3. reduce (one-shot → out; two-shot → my slice of my result buffer, barrier "mid", gather → out);
 //   4. barrier "end": nobody may overwrite staging/result before every peer has finished reading.
 // Flags are system-scope release/acquire atomics on *uncached* memory (hipExtMallocWithFlags); data
-// stores are followed by __threadfence_system() before the flag that publishes them.  Every spin is
-// bounded: on timeout the kernel raises `error` in its Signal block and finishes (the host checks the
-// word and falls back to RCCL) — a lost peer can never hang the GPU.
+// stores are followed by a system-scope release fence before the flag that publishes them.  Every spin is
+// bounded: on timeout the kernel raises `error` in its Signal block and finishes.  The host copies
+// that word back behind every step (`ar_error_async`, no synchronisation) and, when it is set,
+// switches the whole TP group to the library collectives for good — a lost peer can never hang the GPU.
+// Flags are compared as "epoch reached" (signed distance ≥ 0), so a rank that timed out once cannot
+// leave its peers waiting for an epoch that has already gone by.
 // Reduction order is rank 0..N-1 on every rank, so all ranks obtain bit-identical sums.
+//
+// Launch shape (workgroups, one-/two-shot switch point) is a run-time table (`ar_set_tuning`) filled by
+// the start-up sweep in parallel/custom_all_reduce.py; every rank of a group must install the same
+// table (a block synchronises with the same block index on its peers).
 #include <algorithm>
 #include <cstring>
 
@@ -28,7 +41,9 @@
 namespace dli {
 
 constexpr int kMaxRanks = 8;
-constexpr int kMaxBlocks = 64;
+constexpr int kMaxBlocks = 128;
+constexpr int kThreads = 512;
+constexpr int kMaxTuning = 24;
 constexpr unsigned kSpinLimit = 4u * 1000u * 1000u;   // ≈ seconds of polling, then give up with `error` set
 
 struct Signal {
@@ -49,6 +64,13 @@ struct ARState {
   Peers peers;
   int rank, world;
   size_t max_bytes;
+  // launch-shape table: first entry with bytes <= thr wins; past the last entry the defaults apply
+  int n_tuning;
+  int64_t thr[kMaxTuning];
+  int algo[kMaxTuning];     // 1 one-shot, 2 two-shot
+  int blocks[kMaxTuning];
+  int default_blocks;
+  int64_t one_shot_max_bytes;
 };
 
 template <int PHASE>   // 0 start, 1 mid, 2 end
@@ -69,7 +91,7 @@ __device__ __forceinline__ void mesh_barrier(const Peers& p, int rank, int world
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(dst, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     unsigned spins = 0;
-    while (__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != flag) {
+    while ((int32_t)(__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - flag) < 0) {
       if (++spins > kSpinLimit) {
         __hip_atomic_store(&self->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
@@ -93,9 +115,26 @@ __device__ __forceinline__ bf16x8 pack(const float (&acc)[8]) {
   return o;
 }
 
-template <bool TWO_SHOT>
-__global__ __launch_bounds__(512) void all_reduce_kernel(Peers p, int rank, int world, const uint16_t* __restrict__ in,
-                                                         uint16_t* __restrict__ out, int64_t n_vec) {
+// Sum of element i over the staging buffers of all ranks, in rank order.  W > 0: all loads issued first.
+template <int W>
+__device__ __forceinline__ bf16x8 reduce_at(const Peers& p, int world, int64_t i) {
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if constexpr (W > 0) {
+    bf16x8 v[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) v[r] = reinterpret_cast<const bf16x8*>(p.staging[r])[i];
+#pragma unroll
+    for (int r = 0; r < W; ++r) accum(acc, v[r]);
+  } else {
+    for (int r = 0; r < world; ++r) accum(acc, reinterpret_cast<const bf16x8*>(p.staging[r])[i]);
+  }
+  return pack(acc);
+}
+
+template <int W, bool TWO_SHOT>
+__global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers p, int rank, int world_rt, const uint16_t* __restrict__ in,
+                                                              uint16_t* __restrict__ out, int64_t n_vec) {
+  const int world = W > 0 ? W : world_rt;
   Signal* self = p.signal[rank];
   const uint32_t flag = self->epoch[blockIdx.x] + 1;
   const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -108,27 +147,35 @@ __global__ __launch_bounds__(512) void all_reduce_kernel(Peers p, int rank, int 
 
   bf16x8* dst = reinterpret_cast<bf16x8*>(out);
   if (!TWO_SHOT) {
-    for (int64_t i = tid; i < n_vec; i += stride) {
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int r = 0; r < world; ++r) accum(acc, reinterpret_cast<const bf16x8*>(p.staging[r])[i]);
-      dst[i] = pack(acc);
-    }
+    for (int64_t i = tid; i < n_vec; i += stride) dst[i] = reduce_at<W>(p, world, i);
   } else {
-    const int64_t per = (n_vec + world - 1) / world;        // slice r = [r*per, min((r+1)*per, n_vec))
-    const int64_t lo = rank * per, hi = min(lo + per, n_vec);
+    // slice r = [r*per, min((r+1)*per, n_vec)).  Slice-local index j is handled by the SAME (block, thread) on
+    // every rank in every phase, so the per-block barriers order exactly the data each block consumes.
+    const int64_t per = (n_vec + world - 1) / world;
+    const int64_t lo = rank * per;
+    const int64_t cnt = max((int64_t)0, min(per, n_vec - lo));
     bf16x8* res = reinterpret_cast<bf16x8*>(p.result[rank]);
-    // index i is handled by the SAME (block, thread) on every rank in every phase, so the per-block
-    // barriers order exactly the data each block consumes
-    for (int64_t i = tid; i < hi; i += stride) {
-      if (i < lo) continue;
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int r = 0; r < world; ++r) accum(acc, reinterpret_cast<const bf16x8*>(p.staging[r])[i]);
-      res[i] = pack(acc);
-    }
+    for (int64_t j = tid; j < cnt; j += stride) res[lo + j] = reduce_at<W>(p, world, lo + j);
     mesh_barrier<1>(p, rank, world, flag);
-    for (int64_t i = tid; i < n_vec; i += stride) {
-      const int owner = (int)(i / per);
-      dst[i] = reinterpret_cast<const bf16x8*>(p.result[owner])[i];
+    for (int64_t j = tid; j < per; j += stride) {
+      if constexpr (W > 0) {
+        bf16x8 v[W];
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+          const int64_t i = r * per + j;
+          if (i < n_vec) v[r] = reinterpret_cast<const bf16x8*>(p.result[r])[i];
+        }
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+          const int64_t i = r * per + j;
+          if (i < n_vec) dst[i] = v[r];
+        }
+      } else {
+        for (int r = 0; r < world; ++r) {
+          const int64_t i = r * per + j;
+          if (i < n_vec) dst[i] = reinterpret_cast<const bf16x8*>(p.result[r])[i];
+        }
+      }
     }
   }
   mesh_barrier<2>(p, rank, world, flag);
@@ -137,8 +184,8 @@ __global__ __launch_bounds__(512) void all_reduce_kernel(Peers p, int rank, int 
 
 // All-gather with the same protocol: out[r][i] = in_r[i] (rank-major).  Used for the vocab-parallel logits so
 // that a TP decode graph contains no library collective at all.
-__global__ __launch_bounds__(512) void all_gather_kernel(Peers p, int rank, int world, const uint16_t* __restrict__ in,
-                                                         uint16_t* __restrict__ out, int64_t n_vec) {
+__global__ __launch_bounds__(kThreads) void all_gather_kernel(Peers p, int rank, int world, const uint16_t* __restrict__ in,
+                                                              uint16_t* __restrict__ out, int64_t n_vec) {
   Signal* self = p.signal[rank];
   const uint32_t flag = self->epoch[blockIdx.x] + 1;
   const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -151,6 +198,28 @@ __global__ __launch_bounds__(512) void all_gather_kernel(Peers p, int rank, int 
   for (int r = 0; r < world; ++r) {
     const bf16x8* peer = reinterpret_cast<const bf16x8*>(p.staging[r]);
     for (int64_t i = tid; i < n_vec; i += stride) dst[r * n_vec + i] = peer[i];
+  }
+  mesh_barrier<2>(p, rank, world, flag);
+  if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+}
+
+// Broadcast from `root` (any dtype, whole 16-byte vectors): the driver's packed step buffer reaches the TP
+// workers without a library collective.  `buf` is read on the root and written everywhere else.
+__global__ __launch_bounds__(kThreads) void broadcast_kernel(Peers p, int rank, int world, int root, uint16_t* __restrict__ buf,
+                                                             int64_t n_vec) {
+  Signal* self = p.signal[rank];
+  const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bf16x8* mine = reinterpret_cast<bf16x8*>(buf);
+  if (rank == root) {
+    bf16x8* stage = reinterpret_cast<bf16x8*>(p.staging[rank]);
+    for (int64_t i = tid; i < n_vec; i += stride) stage[i] = mine[i];
+  }
+  mesh_barrier<0>(p, rank, world, flag);
+  if (rank != root) {
+    const bf16x8* peer = reinterpret_cast<const bf16x8*>(p.staging[root]);
+    for (int64_t i = tid; i < n_vec; i += stride) mine[i] = peer[i];
   }
   mesh_barrier<2>(p, rank, world, flag);
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
@@ -177,14 +246,19 @@ void* ar_ipc_open(const void* handle64) {
   if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return nullptr;
   return p;
 }
+int ar_ipc_close(void* p) { return (int)hipIpcCloseMemHandle(p); }
 size_t ar_signal_bytes() { return sizeof(Signal); }
+int ar_max_blocks() { return kMaxBlocks; }
 
 void* ar_create(int rank, int world, const int64_t* staging, const int64_t* result, const int64_t* signal, size_t max_bytes) {
-  if (world > kMaxRanks) return nullptr;
+  if (world > kMaxRanks || world < 2 || rank < 0 || rank >= world) return nullptr;
   ARState* s = new ARState();
   s->rank = rank;
   s->world = world;
   s->max_bytes = max_bytes;
+  s->n_tuning = 0;
+  s->default_blocks = 64;
+  s->one_shot_max_bytes = 256 * 1024;
   for (int r = 0; r < world; ++r) {
     s->peers.staging[r] = reinterpret_cast<uint16_t*>(staging[r]);
     s->peers.result[r] = reinterpret_cast<uint16_t*>(result[r]);
@@ -194,37 +268,94 @@ void* ar_create(int rank, int world, const int64_t* staging, const int64_t* resu
 }
 void ar_destroy(void* st) { delete reinterpret_cast<ARState*>(st); }
 
-int ar_error(void* st) {      // host-side check of the timeout word (synchronises the stream by itself: call off the hot path)
+int ar_set_tuning(void* st, int n, const int64_t* thr, const int* algo, const int* blocks, int default_blocks,
+                  int64_t one_shot_max_bytes) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  if (n < 0 || n > kMaxTuning) return -1;
+  for (int i = 0; i < n; ++i) {
+    if ((algo[i] != 1 && algo[i] != 2) || blocks[i] < 1 || blocks[i] > kMaxBlocks) return -1;
+    if (i > 0 && thr[i] <= thr[i - 1]) return -1;
+  }
+  if (default_blocks < 1 || default_blocks > kMaxBlocks) return -1;
+  s->n_tuning = n;
+  for (int i = 0; i < n; ++i) {
+    s->thr[i] = thr[i];
+    s->algo[i] = algo[i];
+    s->blocks[i] = blocks[i];
+  }
+  s->default_blocks = default_blocks;
+  s->one_shot_max_bytes = one_shot_max_bytes;
+  return 0;
+}
+
+int ar_error(void* st) {      // blocking host read of the timeout word (tests, shutdown)
   ARState* s = reinterpret_cast<ARState*>(st);
   uint32_t v = 0;
   (void)hipMemcpy(&v, &s->peers.signal[s->rank]->error, sizeof(v), hipMemcpyDeviceToHost);
   return (int)v;
 }
 
-int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, hipStream_t stream) {
+// stream-ordered copy of the timeout word into pinned host memory: read it after the step's event
+int ar_error_async(void* st, void* pinned_dst4, hipStream_t stream) {
   ARState* s = reinterpret_cast<ARState*>(st);
-  if (bytes % 16 != 0 || (size_t)bytes > s->max_bytes) return -1;
+  return (int)hipMemcpyAsync(pinned_dst4, &s->peers.signal[s->rank]->error, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+}
+
+static int clamp_blocks(int64_t n_vec, int blocks) {
+  const int64_t need = (n_vec + kThreads - 1) / kThreads;
+  return (int)std::max<int64_t>(1, std::min<int64_t>({need, (int64_t)blocks, (int64_t)kMaxBlocks}));
+}
+
+template <bool TWO>
+static void launch_ar(const ARState* s, int blocks, const void* in, void* out, int64_t n_vec, hipStream_t stream) {
+  const uint16_t* i = (const uint16_t*)in;
+  uint16_t* o = (uint16_t*)out;
+  switch (s->world) {
+    case 2: hipLaunchKernelGGL((all_reduce_kernel<2, TWO>), dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, 2, i, o, n_vec); break;
+    case 4: hipLaunchKernelGGL((all_reduce_kernel<4, TWO>), dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, 4, i, o, n_vec); break;
+    case 8: hipLaunchKernelGGL((all_reduce_kernel<8, TWO>), dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, 8, i, o, n_vec); break;
+    default: hipLaunchKernelGGL((all_reduce_kernel<0, TWO>), dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, s->world, i, o, n_vec);
+  }
+}
+
+// algo: 0 = table / default, 1 one-shot, 2 two-shot.  blocks: 0 = table / default.
+int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, int blocks, hipStream_t stream) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  if (bytes <= 0 || bytes % 16 != 0 || (size_t)bytes > s->max_bytes) return -1;
   const int64_t n_vec = bytes / 16;
-  int blocks = (int)std::min<int64_t>((n_vec + 511) / 512, 36);
-  if (blocks < 1) blocks = 1;
-  const bool two = algo == 2 || (algo == 0 && bytes > 256 * 1024 && s->world > 2);
-  if (two)
-    hipLaunchKernelGGL(all_reduce_kernel<true>, dim3(blocks), dim3(512), 0, stream, s->peers, s->rank, s->world,
-                       (const uint16_t*)in, (uint16_t*)out, n_vec);
+  int t_algo = 0, t_blocks = s->default_blocks;
+  for (int i = 0; i < s->n_tuning; ++i)
+    if (bytes <= s->thr[i]) {
+      t_algo = s->algo[i];
+      t_blocks = s->blocks[i];
+      break;
+    }
+  if (algo == 0) algo = t_algo ? t_algo : (bytes > s->one_shot_max_bytes && s->world > 2 ? 2 : 1);
+  blocks = clamp_blocks(n_vec, blocks > 0 ? blocks : t_blocks);
+  if (algo == 2)
+    launch_ar<true>(s, blocks, in, out, n_vec, stream);
   else
-    hipLaunchKernelGGL(all_reduce_kernel<false>, dim3(blocks), dim3(512), 0, stream, s->peers, s->rank, s->world,
-                       (const uint16_t*)in, (uint16_t*)out, n_vec);
+    launch_ar<false>(s, blocks, in, out, n_vec, stream);
   return 0;
 }
 
 int launch_all_gather(void* st, const void* in, void* out, int64_t bytes, hipStream_t stream) {
   ARState* s = reinterpret_cast<ARState*>(st);
-  if (bytes % 16 != 0 || (size_t)bytes > s->max_bytes) return -1;
+  if (bytes <= 0 || bytes % 16 != 0 || (size_t)bytes > s->max_bytes) return -1;
   const int64_t n_vec = bytes / 16;
-  int blocks = (int)std::min<int64_t>((n_vec + 511) / 512, 36);
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(all_gather_kernel, dim3(blocks), dim3(512), 0, stream, s->peers, s->rank, s->world, (const uint16_t*)in,
+  const int blocks = clamp_blocks(n_vec, s->default_blocks);
+  hipLaunchKernelGGL(all_gather_kernel, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, s->world, (const uint16_t*)in,
                      (uint16_t*)out, n_vec);
+  return 0;
+}
+
+int launch_broadcast(void* st, void* buf, int64_t bytes, int root, hipStream_t stream) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  if (bytes <= 0 || bytes % 16 != 0 || (size_t)bytes > s->max_bytes || root < 0 || root >= s->world) return -1;
+  const int64_t n_vec = bytes / 16;
+  const int blocks = clamp_blocks(n_vec, s->default_blocks);
+  hipLaunchKernelGGL(broadcast_kernel, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, s->world, root, (uint16_t*)buf,
+                     n_vec);
   return 0;
 }
 

@@ -55,8 +55,14 @@ void* ar_ipc_open(const void* handle64);
 size_t ar_signal_bytes();
 void* ar_create(int rank, int world, const int64_t* staging, const int64_t* result, const int64_t* signal, size_t max_bytes);
 void ar_destroy(void* st);
+int ar_ipc_close(void* p);
+int ar_max_blocks();
+int ar_set_tuning(void* st, int n, const int64_t* thr, const int* algo, const int* blocks, int default_blocks,
+                  int64_t one_shot_max_bytes);
 int ar_error(void* st);
-int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, hipStream_t stream);
+int ar_error_async(void* st, void* pinned_dst4, hipStream_t stream);
+int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, int blocks, hipStream_t stream);
 int launch_all_gather(void* st, const void* in, void* out, int64_t bytes, hipStream_t stream);
+int launch_broadcast(void* st, void* buf, int64_t bytes, int root, hipStream_t stream);
 
 }  // namespace dli

@@ -293,14 +293,43 @@ int64_t ar_create(int64_t rank, int64_t world, const Tensor& staging, const Tens
 }
 void ar_destroy(int64_t st) { dli::ar_destroy(reinterpret_cast<void*>(st)); }
 int64_t ar_error(int64_t st) { return dli::ar_error(reinterpret_cast<void*>(st)); }
-void ar_all_reduce(int64_t st, const Tensor& inp, Tensor out, int64_t algo) {
+void ar_all_reduce(int64_t st, const Tensor& inp, Tensor out, int64_t algo, int64_t blocks) {
   TORCH_CHECK(inp.is_cuda() && out.is_cuda() && inp.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16);
   TORCH_CHECK(inp.is_contiguous() && out.is_contiguous() && inp.numel() == out.numel());
   TORCH_CHECK(reinterpret_cast<uintptr_t>(inp.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0);
   const int rc = dli::launch_all_reduce(reinterpret_cast<void*>(st), inp.data_ptr(), out.data_ptr(), inp.numel() * 2, (int)algo,
-                                        cur_stream(inp));
+                                        (int)blocks, cur_stream(inp));
   TORCH_CHECK(rc == 0, "custom all-reduce: message of ", inp.numel() * 2, " bytes not supported");
 }
+
+// launch-shape table chosen by the start-up sweep (identical on every rank of the group)
+void ar_set_tuning(int64_t st, const Tensor& thr, const Tensor& algo, const Tensor& blocks, int64_t default_blocks,
+                   int64_t one_shot_max_bytes) {
+  TORCH_CHECK(!thr.is_cuda() && thr.scalar_type() == at::kLong && thr.is_contiguous());
+  TORCH_CHECK(!algo.is_cuda() && algo.scalar_type() == at::kInt && algo.is_contiguous() && algo.numel() == thr.numel());
+  TORCH_CHECK(!blocks.is_cuda() && blocks.scalar_type() == at::kInt && blocks.is_contiguous() && blocks.numel() == thr.numel());
+  const int rc = dli::ar_set_tuning(reinterpret_cast<void*>(st), (int)thr.numel(), thr.data_ptr<int64_t>(), algo.data_ptr<int>(),
+                                    blocks.data_ptr<int>(), (int)default_blocks, one_shot_max_bytes);
+  TORCH_CHECK(rc == 0, "ar_set_tuning: invalid table");
+}
+
+// queue a copy of the kernel's timeout word into `pinned` (int32[1], pinned host memory) on the current stream
+void ar_error_async(int64_t st, Tensor pinned) {
+  TORCH_CHECK(!pinned.is_cuda() && pinned.is_pinned() && pinned.scalar_type() == at::kInt && pinned.numel() >= 1);
+  const auto stream = c10::hip::getCurrentHIPStream().stream();
+  const int rc = dli::ar_error_async(reinterpret_cast<void*>(st), pinned.data_ptr(), stream);
+  TORCH_CHECK(rc == 0, "ar_error_async: hipMemcpyAsync failed with code ", rc);
+}
+
+// in place broadcast of `buf` (any dtype, byte size a multiple of 16) from TP rank `root`
+void ar_broadcast(int64_t st, Tensor buf, int64_t root) {
+  TORCH_CHECK(buf.is_cuda() && buf.is_contiguous() && reinterpret_cast<uintptr_t>(buf.data_ptr()) % 16 == 0);
+  const int64_t bytes = buf.numel() * buf.element_size();
+  const int rc = dli::launch_broadcast(reinterpret_cast<void*>(st), buf.data_ptr(), bytes, (int)root, cur_stream(buf));
+  TORCH_CHECK(rc == 0, "custom broadcast: message of ", bytes, " bytes not supported");
+}
+void ar_ipc_close(int64_t ptr) { (void)dli::ar_ipc_close(reinterpret_cast<void*>(ptr)); }
+int64_t ar_max_blocks() { return dli::ar_max_blocks(); }
 
 void ar_all_gather(int64_t st, const Tensor& inp, Tensor out) {
   TORCH_CHECK(inp.is_cuda() && out.is_cuda() && inp.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16);
@@ -322,7 +351,13 @@ TORCH_LIBRARY(dli, m) {
   m.def("ar_create(int rank, int world, Tensor staging, Tensor result, Tensor signal, int max_bytes) -> int", &ar_create);
   m.def("ar_destroy(int state) -> ()", &ar_destroy);
   m.def("ar_error(int state) -> int", &ar_error);
-  m.def("ar_all_reduce(int state, Tensor inp, Tensor(a!) out, int algo) -> ()", &ar_all_reduce);
+  m.def("ar_all_reduce(int state, Tensor inp, Tensor(a!) out, int algo, int blocks=0) -> ()", &ar_all_reduce);
+  m.def("ar_set_tuning(int state, Tensor thr, Tensor algo, Tensor blocks, int default_blocks, int one_shot_max_bytes) -> ()",
+        &ar_set_tuning);
+  m.def("ar_error_async(int state, Tensor(a!) pinned) -> ()", &ar_error_async);
+  m.def("ar_broadcast(int state, Tensor(a!) buf, int root) -> ()", &ar_broadcast);
+  m.def("ar_ipc_close(int ptr) -> ()", &ar_ipc_close);
+  m.def("ar_max_blocks() -> int", &ar_max_blocks);
   m.def("ar_all_gather(int state, Tensor inp, Tensor(a!) out) -> ()", &ar_all_gather);
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);

@@ -95,7 +95,7 @@ def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
                 chan.send(("dead", traceback.format_exc()))
                 raise
             if outs:
-                chan.send(("out", [(o.req_id, o.new_token_ids[0], o.finished, o.finish_reason, o.num_prompt_tokens,
+                chan.send(("out", [(o.req_id, o.new_token_ids[0] if o.new_token_ids else None, o.finished, o.finish_reason, o.num_prompt_tokens,
                                     o.num_output_tokens, o.num_cached_tokens) for o in outs]))
     engine.shutdown()
 

@@ -37,6 +37,8 @@ class LLMEngine:
         self.requests: dict[str, Request] = {}
         self._seq_ids = itertools.count(1)
         self._inflight = None
+        self._warmed = False
+        self._last_result_time = 0.0
         self.async_scheduling = self._default_async() if cfg.async_scheduling is None else bool(cfg.async_scheduling)
         if self.ctx.is_driver:
             self.bm = BlockManager(self.runner.num_blocks, KV_BLOCK_SIZE, cfg.cache.enable_prefix_caching)
@@ -115,6 +117,8 @@ class LLMEngine:
         drains between steps.  Ids the host has not seen yet are fed from the sampler's device buffer
         (``ops.gather_sampled``); an EOS discovered one step late costs one discarded token.
         Unpipelined: schedule → run → wait → outputs, nothing in flight between calls."""
+        if not self._warmed and self.ctx.tp_size > 1:
+            self.warmup()                                    # the TP workers are waiting in theirs (collective)
         t0 = time.perf_counter()
         with trace_range("schedule"):
             batch = self.scheduler.schedule()
@@ -127,10 +131,8 @@ class LLMEngine:
             if self.ctx.tp_size > 1 and self.metrics.steps % 128 == 0:
                 from ..runtime.tp_launcher import check_children
                 check_children()                             # a dead TP worker would hang the next collective
-                ar = getattr(self.ctx, "custom_ar", None)
-                if ar is not None and ar.enabled and ar.error():
-                    # a peer never raised its flag: the kernel gave up after its bounded spin, sums are not trustworthy
-                    raise RuntimeError("custom all-reduce timed out waiting for a peer GPU; aborting the engine")
+                # (a timed-out custom all-reduce is seen behind EVERY step without a sync and switches the group to
+                #  the library collectives with the next step header: ModelRunner._note_ar_error / _broadcast_step)
             with trace_range(f"launch[T={batch.total_tokens},B={len(batch.requests)}]"):
                 handle = self.runner.launch(batch, self.bm)
                 self.scheduler.advance(batch, self.cfg.sched.max_model_len)
@@ -139,7 +141,22 @@ class LLMEngine:
             prev, self._inflight = self._inflight, launched
         else:
             prev = launched
-        return self._finish_step(prev) if prev is not None else []
+        outs = self._finish_step(prev) if prev is not None else []
+        if self.scheduler.shed:
+            outs += self._report_shed()
+        return outs
+
+    def _report_shed(self) -> list[RequestOutput]:
+        """Requests the scheduler gave up on (``max_queue_delay``): one final record each, no token."""
+        outs = []
+        for req in self.scheduler.shed:
+            self.requests.pop(req.req_id, None)
+            self.metrics.on_finish(req, aborted=True)
+            self.metrics.requests_shed += 1
+            outs.append(RequestOutput(req.req_id, [], True, RequestStatus.FINISHED_SHED.value, req.num_prompt, 0, 0,
+                                      req.client_tag))
+        self.scheduler.shed.clear()
+        return outs
 
     def _finish_step(self, inflight) -> list[RequestOutput]:
         batch, handle, sched_s, t_launch = inflight
@@ -165,6 +182,11 @@ class LLMEngine:
                                       req.num_output, req.num_cached_prompt, req.client_tag))
         # exec = launch → ids on the host (GPU time of the step as the caller sees it)
         self.metrics.on_step(batch, sched_s, t2 - t_launch, time.perf_counter() - t2, self)
+        # step-time feedback for the TPOT controller: with a step queued behind this one the GPU never idles, so the
+        # time between two consecutive results IS the step time; otherwise launch → result
+        dt = t2 - max(t_launch, self._last_result_time) if self._last_result_time else t2 - t_launch
+        self._last_result_time = t2
+        self.scheduler.observe_step(dt, batch.total_tokens)
         return outs
 
     # ------------------------------------------------------------------ conveniences
@@ -183,9 +205,18 @@ class LLMEngine:
         return [reqs[rid].output_ids.tolist() for rid in ids]
 
     def warmup(self, capture_graphs: bool = True):
-        """Compile/capture everything that would otherwise hit the first requests' latency."""
+        """Compile/capture everything that would otherwise hit the first requests' latency, then check the fast
+        paths against their plain counterparts (``ModelRunner.startup_selftest``).  Under TP every rank calls this
+        (the captures and the checks contain collectives); the host barriers bound the rank skew seen by the first
+        spin-waiting all-reduce kernel."""
+        self._warmed = True
+        self.ctx.barrier()
         if capture_graphs:
             self.runner.capture_all()
+        self.runner.startup_selftest()
+        self.ctx.barrier()
 
     def shutdown(self):
+        if not self._warmed and self.ctx.tp_size > 1 and self.ctx.is_driver:
+            self.warmup()                                    # release the workers from their warm-up barrier first
         self.runner.shutdown_workers()

@@ -18,6 +18,7 @@ class RequestStatus(enum.Enum):
     FINISHED_STOPPED = "stop"          # EOS / stop token
     FINISHED_LENGTH = "length"         # max_tokens or max_model_len
     FINISHED_ABORTED = "abort"
+    FINISHED_SHED = "shed"             # overload: waited longer than max_queue_delay without being admitted
 
     @property
     def finished(self) -> bool:

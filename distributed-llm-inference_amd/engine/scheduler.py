@@ -16,6 +16,12 @@ Policy, one call per engine step:
 3. **Preemption by recompute**: if a running sequence cannot get a page, the most recently admitted
    sequence is evicted (pages freed, progress reset, put at the head of the waiting queue).  With
    288 GB of HBM recompute is cheaper than swap.
+4. **SLO control** (optional): ``ttft_slo`` — requests already past their TTFT deadline yield to fresher
+   ones (under overload FCFS makes every request late); ``max_queue_delay`` — a request that still has
+   not been admitted after that long is shed (finished with an error) instead of waiting for ever;
+   ``tpot_slo`` — the engine feeds measured step times back (``observe_step``) and the prefill share
+   of the token budget follows them, so that a burst of prompts cannot stretch the inter-token time of
+   the running decodes past the target; when even the decode-only step is too slow, admission pauses.
 
 KV accounting lives in the C++ ``BlockManager`` (``csrc/runtime/block_manager.cpp``).
 """
@@ -40,6 +46,11 @@ class Scheduler:
         self.running: list[Request] = []
         self.watermark_blocks = max(int(block_manager.num_blocks * watermark), 1)
         self.num_preemptions = 0
+        self.shed: list[Request] = []                      # finished with status "shed"; the engine reports them
+        self.num_shed = 0
+        # TPOT controller state
+        self.dyn_budget = cfg.max_num_batched_tokens        # current total-token target of a step
+        self.step_ema: Optional[float] = None
 
     # ------------------------------------------------------------------ queue management
     def add(self, req: Request) -> None:
@@ -89,18 +100,67 @@ class Scheduler:
         self.num_preemptions += 1
         self.waiting.appendleft(req)
 
+    # ------------------------------------------------------------------ TPOT control
+    def observe_step(self, seconds: float, tokens: int) -> None:
+        """Feedback from the engine: wall time of a finished step and the tokens it computed.  Multiplicative
+        control of the step's token target towards ``tpot_slo · tpot_slo_margin`` seconds per step."""
+        cfg = self.cfg
+        if cfg.tpot_slo is None or seconds <= 0:
+            return
+        self.step_ema = seconds if self.step_ema is None else 0.6 * self.step_ema + 0.4 * seconds
+        target = cfg.tpot_slo * cfg.tpot_slo_margin
+        ratio = target / seconds
+        if ratio < 1.0:                                    # too slow: shrink relative to what the step really held
+            basis = min(self.dyn_budget, max(tokens, 1))
+            new = basis * max(ratio, 0.6)
+        else:                                              # head-room: grow gently (a burst arrives faster than it leaves)
+            new = self.dyn_budget * min(ratio, 1.1)
+        self.dyn_budget = int(min(max(new, cfg.min_prefill_tokens), cfg.max_num_batched_tokens))
+
+    def _shed_overdue(self, now: float) -> None:
+        lim = self.cfg.max_queue_delay
+        if lim is None:
+            return
+        for q in (self.late, self.waiting):
+            # arrival order: overdue requests sit at the head; preempted/partly generated ones are never shed
+            while q and q[0].arrival < now - lim and q[0].num_output == 0 and q[0].preemptions == 0:
+                req = q.popleft()
+                if self.bm.has_seq(req.seq_id):
+                    self.bm.free_seq(req.seq_id)
+                req.status = RequestStatus.FINISHED_SHED
+                self.shed.append(req)
+                self.num_shed += 1
+
     # ------------------------------------------------------------------ one step
     def schedule(self) -> Optional[ScheduledBatch]:
         cfg = self.cfg
         budget = cfg.max_num_batched_tokens
         picked: list[tuple[Request, int]] = []
         preempted: list[Request] = []
+        now = time.perf_counter()
+        self._shed_overdue(now)
+        # prefill share of this step: everything (no TPOT target), or what the controller leaves after the decodes
+        prefill_left = budget
+        admit = True
+        if cfg.tpot_slo is not None:
+            n_dec = sum(1 for r in self.running if r.num_tokens - r.num_computed == 1)
+            prefill_left = max(self.dyn_budget - n_dec, 0)
+            if self.step_ema is not None and self.step_ema > cfg.tpot_slo and self.dyn_budget <= cfg.min_prefill_tokens:
+                admit = False                              # the decode population alone is over the target
+            elif prefill_left < cfg.min_prefill_tokens:
+                prefill_left = cfg.min_prefill_tokens       # keep prompts trickling in while decodes meet the target
 
         # 1) running sequences
         i = 0
         while i < len(self.running) and budget > 0:
             req = self.running[i]
-            n_new = min(req.num_tokens - req.num_computed, cfg.long_prefill_chunk, budget)
+            remaining = req.num_tokens - req.num_computed
+            n_new = min(remaining, cfg.long_prefill_chunk, budget)
+            if remaining > 1:                               # a prefill chunk competes for the prefill share
+                n_new = min(n_new, prefill_left)
+                if n_new <= 0:
+                    i += 1
+                    continue
             ok = True
             while not self.bm.allocate(req.seq_id, req.num_computed + n_new):
                 victim = self.running.pop()                # most recently admitted
@@ -114,37 +174,46 @@ class Scheduler:
                 break
             picked.append((req, n_new))
             budget -= n_new
+            if remaining > 1:
+                prefill_left -= n_new
             i += 1
 
         # 2) admission (never in a step that had to preempt)
         if cfg.ttft_slo is not None and self.waiting:
-            deadline = time.perf_counter() - cfg.ttft_slo * (1.0 - cfg.ttft_slo_margin)
+            deadline = now - cfg.ttft_slo * (1.0 - cfg.ttft_slo_margin)
             while self.waiting and self.waiting[0].arrival < deadline and self.waiting[0].num_output == 0 \
                     and self.waiting[0].preemptions == 0:
                 self.late.append(self.waiting.popleft())    # arrival order = deadline order: late ones sit at the head
-        if not preempted:
-            while (self.waiting or self.late) and budget > 0 and len(self.running) < cfg.max_num_seqs:
+        if not preempted and admit:
+            while (self.waiting or self.late) and budget > 0 and prefill_left > 0 and len(self.running) < cfg.max_num_seqs:
                 queue = self.waiting if self.waiting else self.late
                 req = queue[0]
+                matched_now = False
                 if not self.bm.has_seq(req.seq_id):
                     cached = self.bm.match_prefix(req.seq_id, req.all_ids)
+                    matched_now = True
                     req.num_computed = cached
                     if req.preemptions == 0:
                         req.num_cached_prompt = cached
                 remaining = req.num_tokens - req.num_computed
-                n_new = min(remaining, cfg.long_prefill_chunk, budget)
-                if not cfg.enable_chunked_prefill and n_new < remaining:
-                    break
+                n_new = min(remaining, cfg.long_prefill_chunk, budget, prefill_left)
                 need_total = req.num_computed + n_new
                 free_after = self.bm.num_free - max((need_total + self.bm.block_size - 1) // self.bm.block_size
                                                     - len(self.bm.block_table(req.seq_id)), 0)
-                if free_after < self.watermark_blocks or not self.bm.allocate(req.seq_id, need_total):
+                if ((not cfg.enable_chunked_prefill and n_new < remaining) or free_after < self.watermark_blocks
+                        or not self.bm.allocate(req.seq_id, need_total)):
+                    if matched_now:
+                        # not admitted after all: drop the references on the matched prefix pages, or a request that
+                        # is only waiting would pin them against eviction (it is matched again at its next attempt)
+                        self.bm.free_seq(req.seq_id)
+                        req.num_computed = 0
                     break
                 queue.popleft()
                 req.status = RequestStatus.RUNNING
                 self.running.append(req)
                 picked.append((req, n_new))
                 budget -= n_new
+                prefill_left -= n_new
 
         if not picked:
             return None

@@ -99,6 +99,7 @@ class RowParallelLinear(nn.Module):
 
     OVERLAP_MIN_ROWS = int(__import__('os').environ.get('DLI_OVERLAP_MIN_ROWS', '1024'))
     OVERLAP_CHUNKS = 4
+    OVERLAP_OK = True          # cleared by ModelRunner.startup_selftest when the pipeline disagrees with the plain path
 
     def __init__(self, in_features: int, out_features: int, ctx: ParallelContext, dtype, device, bias: bool = False,
                  reduce: bool = True):
@@ -111,8 +112,8 @@ class RowParallelLinear(nn.Module):
     def forward(self, x):
         # the bias must be added once, not tp times: only rank 0 adds it before the reduction
         b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
-        if (self.reduce and self.ctx.tp_size > 1 and x.is_cuda and x.dim() == 2 and x.shape[0] >= self.OVERLAP_MIN_ROWS
-                and self._stream_ordered_backend() and not torch.cuda.is_current_stream_capturing()):
+        if (self.reduce and self.OVERLAP_OK and self.ctx.tp_size > 1 and x.is_cuda and x.dim() == 2
+                and x.shape[0] >= self.OVERLAP_MIN_ROWS and self._stream_ordered_backend() and not torch.cuda.is_current_stream_capturing()):
             return self._forward_overlapped(x, b)
         y = ops.linear(x, self.weight.data, b)
         return self.ctx.all_reduce(y) if self.reduce else y
@@ -144,6 +145,9 @@ class RowParallelLinear(nn.Module):
             ready.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
+                c = self.ctx.comm
+                c["ar_lib_calls"] += 1
+                c["ar_lib_bytes"] += (hi - lo) * y.shape[1] * y.element_size()
                 dist.all_reduce(y[lo:hi], group=self.ctx.group)    # RCCL on the comm stream, GEMM i+1 meanwhile
                 ev = torch.cuda.Event()
                 ev.record(side)

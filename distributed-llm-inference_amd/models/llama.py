@@ -5,10 +5,17 @@ O GEMM (+all-reduce) → fused_add_rmsnorm → gate/up GEMM → SwiGLU → down 
 replaces the dense MLP by the top-2 MoE block.  Everything between the GEMMs is a hand-written HIP
 kernel (``dli_amd.ops``); the GEMMs are hipBLASLt through torch.
 
-Expert parallelism (``ctx.ep_size == tp``): each rank owns ``E/tp`` whole experts.  Activations are
-already replicated across the TP group after the attention all-reduce, so no all-to-all dispatch is
-needed — every rank evaluates its own experts on the tokens routed to them and the existing
-all-reduce sums the partial outputs (the "all-gather + local mask" variant noted in SURVEY.md §2.5 K8).
+Expert parallelism (``ctx.ep_size == tp``): each rank owns ``E/tp`` whole experts.  Two dispatch modes
+(SURVEY.md §2.5 K8 "EP dispatch/combine via all-to-all (or all-gather + local mask at small T)"):
+
+* *replicated* (decode-sized steps, hipGraph-capturable): activations are already replicated across the
+  TP group after the attention all-reduce, so every rank evaluates its own experts on the tokens routed
+  to them and one all-reduce of ``[T, H]`` sums the partial outputs;
+* *all-to-all* (steps of ``ctx.ep_a2a_min_tokens`` tokens or more): each rank routes only its ``T/ep``
+  slice of the tokens, sends every (token, expert) row to the rank that owns the expert, runs the grouped
+  GEMM on what it received, returns the expert outputs and combines them; an all-gather of the ``T/ep``
+  result rows replicates the block output.  Per rank that moves ``≈ 2·top_k/ep + 1`` messages of ``T·H/ep``
+  rows' worth instead of the ``≈ 2·(ep-1)/ep · T·H`` of the all-reduce — 3.5× less over xGMI at ep = 8, top-2.
 """
 from __future__ import annotations
 
@@ -104,11 +111,53 @@ class MoEBlock(nn.Module):
             self.w2 = Weight((E, H, I), 2, ctx, dtype, device)
 
     def forward(self, h):
+        ctx = self.ctx
+        if (ctx.ep_size > 1 and 0 < ctx.ep_a2a_min_tokens <= h.shape[0]
+                and not (h.is_cuda and torch.cuda.is_current_stream_capturing())):
+            return self._forward_all_to_all(h)
         logits = self.router(h)
         if _EP_DEBUG and self.ctx.tp_size > 1 and not torch.cuda.is_current_stream_capturing():
             _ep_consistency_check(self.ctx, h, logits)
         out = ops.fused_moe(h, logits, self.w13.data, self.w2.data, self.top_k, self.expert_offset)
         return self.ctx.all_reduce(out)
+
+    def _forward_all_to_all(self, h):
+        """Token-sliced routing + all-to-all dispatch/combine (see the module docstring).  The split sizes of the
+        exchange are data dependent, so the per-destination counts cross the host once per layer (one small D2H +
+        one gloo exchange): this path serves the large eager prefill steps, never a captured decode step."""
+        import torch.distributed as dist
+        ctx, ep, k = self.ctx, self.ctx.tp_size, self.top_k
+        T, H = h.shape
+        per = (T + ep - 1) // ep
+        lo = min(ctx.tp_rank * per, T)
+        hl = h[lo:min(lo + per, T)]
+        n_l = hl.shape[0]
+        probs = torch.softmax(self.router(hl).float(), dim=-1)
+        topv, topi = probs.topk(k, dim=-1)                                   # [n_l, k]
+        topv = topv / topv.sum(-1, keepdim=True)
+        flat_e = topi.reshape(-1)
+        dest = torch.div(flat_e, self.local_experts, rounding_mode="floor")  # owner rank of every (token, k) row
+        order = torch.sort(dest, stable=True).indices
+        send_counts = torch.bincount(dest, minlength=ep).cpu()
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=ctx.cpu_group if ctx.cpu_group is not None else ctx.group)
+        send_n, recv_n = send_counts.tolist(), recv_counts.tolist()
+        tok = torch.div(order, k, rounding_mode="floor")
+        x_recv = ctx.all_to_all(hl.index_select(0, tok), recv_n, send_n)     # rows for my experts, grouped by source
+        e_recv = ctx.all_to_all(flat_e.index_select(0, order).to(torch.int32), recv_n, send_n)
+        R = x_recv.shape[0]
+        if R:
+            # the grouped GEMM takes its expert assignment from router logits: a one-hot row with top-1 selects the
+            # expert that the source rank chose, with weight 1 (the gate weights are applied at the source)
+            onehot = torch.zeros(R, self.num_experts, dtype=h.dtype, device=h.device)
+            onehot.scatter_(1, e_recv.long().unsqueeze(1), 8.0)
+            y = ops.fused_moe(x_recv, onehot, self.w13.data, self.w2.data, 1, self.expert_offset)
+        else:
+            y = x_recv
+        y_back = ctx.all_to_all(y, send_n, recv_n)                            # same order as the rows I sent
+        out_l = torch.zeros(per, H, dtype=torch.float32, device=h.device)
+        out_l.index_add_(0, tok, y_back.float() * topv.reshape(-1).index_select(0, order).unsqueeze(1))
+        return ctx.all_gather_rows(out_l.to(h.dtype))[:T]
 
 
 class DecoderLayer(nn.Module):

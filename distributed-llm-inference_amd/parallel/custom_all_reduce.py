@@ -3,62 +3,92 @@
 Set-up (once per TP group): every rank allocates a staging buffer, a result buffer (plain device
 memory) and a flag block (uncached memory), exports them as HIP IPC handles, the handles are
 all-gathered over the CPU (gloo) group and every rank maps its peers' buffers.  A self-test against
-RCCL decides whether the fast path is enabled; afterwards ``all_reduce`` is a single kernel launch on
-the current stream (capturable in the decode hipGraph).
+sums exchanged over the CPU group decides whether the fast path is enabled; afterwards ``all_reduce``
+/ ``all_gather`` / ``broadcast`` are single kernel launches on the current stream (capturable in the
+decode hipGraph) and a TP step needs no library collective at all.
 
-Used for bf16 messages up to ``max_bytes`` (decode-sized: B·H·2 bytes ≤ 8 MiB); larger prefill
-messages stay on RCCL, whose bandwidth-optimised protocols win there.
+Launch shape is *measured*, not guessed: :meth:`CustomAllReduce.tune` sweeps workgroup counts and the
+one-/two-shot algorithms over 8 KB … ``max_bytes`` inside hipGraphs (what the decode step sees), times
+the library (RCCL) all-reduce on the same sizes when the device group is ``nccl``, installs the
+winning (algorithm, workgroups) per size bucket on every rank and sets ``use_max_bytes`` to the size
+where the library starts to win (bandwidth-optimised protocols win for prefill-sized
+messages).  The sweep runs at start-up of every TP group, so numbers for real xGMI peers appear the
+first time more than one GPU is visible; ``tuning`` keeps the table for the benchmark JSON.
 """
 from __future__ import annotations
+
+import os
+import time
 
 import torch
 import torch.distributed as dist
 
 from .. import ops
 
+_SIZES = (8 << 10, 32 << 10, 128 << 10, 512 << 10, 1 << 20, 2 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20)
+
 
 class CustomAllReduce:
     def __init__(self, ctx, device, max_bytes: int = 32 << 20):
         lib = ops.hip()
         self.lib, self.ctx, self.device, self.max_bytes = lib, ctx, device, max_bytes
+        self.use_max_bytes = max_bytes                      # custom path up to here, library above (set by tune())
         self.world, self.rank = ctx.tp_size, ctx.tp_rank
+        self.tuning: dict = {}
         torch.cuda.set_device(device)
         own = [lib.ar_alloc(max_bytes, False), lib.ar_alloc(max_bytes, False), lib.ar_alloc(lib.ar_signal_bytes(), True)]
         self._own = own
         handles = [lib.ar_ipc_handle(p).tolist() for p in own]
         gathered = [None] * self.world
-        group = ctx.cpu_group if ctx.cpu_group is not None else ctx.group
+        group = self._cpu_group()
         dist.all_gather_object(gathered, handles, group=group)
         tables = [[], [], []]
+        self._opened = []
         for r in range(self.world):
             for k in range(3):
                 if r == self.rank:
                     tables[k].append(own[k])
                 else:
-                    tables[k].append(lib.ar_ipc_open(torch.tensor(gathered[r][k], dtype=torch.uint8)))
+                    p = lib.ar_ipc_open(torch.tensor(gathered[r][k], dtype=torch.uint8))
+                    self._opened.append(p)
+                    tables[k].append(p)
         t = [torch.tensor(x, dtype=torch.int64) for x in tables]
         self.state = lib.ar_create(self.rank, self.world, t[0], t[1], t[2], max_bytes)
         self.enabled = True
+        self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         dist.barrier(group=group)
 
+    def _cpu_group(self):
+        return self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
+
     @classmethod
-    def create(cls, ctx, device, max_bytes: int = 32 << 20):
-        """Returns a verified instance, or ``None`` (→ RCCL only) if set-up or the self-test fails."""
+    def create(cls, ctx, device, max_bytes: int = 32 << 20, tune: bool | None = None):
+        """Returns a verified (and tuned) instance, or ``None`` (→ library collectives only) if set-up or the
+        self-test fails on any rank."""
         try:
             ar = cls(ctx, device, max_bytes)
-            return ar if ar.self_test() else None
+            if not ar.self_test():
+                print(f"[dli_amd] custom all-reduce self-test FAILED on tp rank {ctx.tp_rank}: using the library collectives",
+                      flush=True)
+                return None
+            if tune is None:
+                tune = os.environ.get("DLI_AR_TUNE", "1") != "0"
+            if tune:
+                ar.tune()
+            return ar
         except Exception as e:                              # IPC unavailable, > 8 ranks, …
-            print(f"[dli_amd] custom all-reduce disabled: {e}")
+            print(f"[dli_amd] custom all-reduce disabled: {type(e).__name__}: {e}", flush=True)
             return None
 
+    # ------------------------------------------------------------------ collectives
     def should_use(self, x: torch.Tensor) -> bool:
         return (self.enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
-                and 0 < x.numel() * 2 <= self.max_bytes and (x.numel() * 2) % 16 == 0 and x.data_ptr() % 16 == 0)
+                and 0 < x.numel() * 2 <= self.use_max_bytes and (x.numel() * 2) % 16 == 0 and x.data_ptr() % 16 == 0)
 
-    def all_reduce(self, x: torch.Tensor, algo: int = 0) -> torch.Tensor:
-        """Out-of-place sum over the TP group (``algo``: 0 auto, 1 one-shot, 2 two-shot)."""
+    def all_reduce(self, x: torch.Tensor, algo: int = 0, blocks: int = 0) -> torch.Tensor:
+        """Out-of-place sum over the TP group (``algo``: 0 tuned/auto, 1 one-shot, 2 two-shot)."""
         out = torch.empty_like(x)
-        self.lib.ar_all_reduce(self.state, x, out, algo)
+        self.lib.ar_all_reduce(self.state, x, out, algo, blocks)
         return out
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
@@ -67,15 +97,38 @@ class CustomAllReduce:
         self.lib.ar_all_gather(self.state, x, out)
         return out
 
+    def can_broadcast(self, buf: torch.Tensor) -> bool:
+        nbytes = buf.numel() * buf.element_size()
+        return (self.enabled and buf.is_cuda and buf.is_contiguous() and 0 < nbytes <= self.max_bytes
+                and nbytes % 16 == 0 and buf.data_ptr() % 16 == 0)
+
+    def broadcast(self, buf: torch.Tensor, root: int = 0) -> torch.Tensor:
+        """In place: every rank's ``buf`` becomes the root's."""
+        self.lib.ar_broadcast(self.state, buf, root)
+        return buf
+
+    # ------------------------------------------------------------------ failure detection
     def error(self) -> bool:
+        """Blocking read of the kernels' timeout word (tests, shutdown)."""
         return bool(self.lib.ar_error(self.state))
 
+    def queue_error_check(self) -> None:
+        """Stream-ordered copy of the timeout word into pinned memory; read ``error_seen`` after the step's event."""
+        self.lib.ar_error_async(self.state, self._err_host)
+
+    @property
+    def error_seen(self) -> bool:
+        return bool(self._err_host[0].item())
+
+    # ------------------------------------------------------------------ self-test
     def self_test(self) -> bool:
         """Compare against sums exchanged over the CPU group (works whatever the device backend is)."""
         ok = True
-        group = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
+        group = self._cpu_group()
         g = torch.Generator().manual_seed(1234 + self.rank)
-        for numel, algo in ((4096, 1), (1 << 20, 2), (3 * 4096 + 8, 2), (1 << 18, 0)):
+        for numel, algo in ((4096, 1), (1 << 20, 2), (3 * 4096 + 8, 2), (1 << 18, 0), (1 << 18, 1)):
+            if numel * 2 > self.max_bytes:
+                continue
             x_cpu = torch.randn(numel, generator=g).to(torch.bfloat16)
             parts = [None] * self.world
             dist.all_gather_object(parts, x_cpu, group=group)
@@ -85,10 +138,111 @@ class CustomAllReduce:
             gathered = self.all_gather(x).cpu()
             ok &= bool(torch.allclose(got, want, rtol=2e-2, atol=2e-2)) and not self.error()
             ok &= all(torch.equal(gathered[r], parts[r]) for r in range(self.world))
+            b = (x if self.rank == 0 else torch.zeros_like(x)).view(torch.int32).clone()
+            self.broadcast(b, 0)
+            ok &= bool(torch.equal(b.cpu(), parts[0].view(torch.int32)))
         votes = [None] * self.world
-        dist.all_gather_object(votes, ok, group=group)
+        dist.all_gather_object(votes, bool(ok), group=group)
         self.enabled = all(votes)
         return self.enabled
+
+    # ------------------------------------------------------------------ launch-shape sweep
+    def _time_graph(self, fn, iters: int) -> float:
+        """µs per call of ``fn`` replayed ``iters`` times inside one hipGraph (pure GPU time, as in a decode step)."""
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+        torch.cuda.synchronize()
+        dist.barrier(group=self._cpu_group())
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g.replay()                                           # aligns the GPUs of the group (host skew ends up in here) …
+        a.record()
+        g.replay()                                           # … so this one, queued behind it, is pure kernel time
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / iters
+
+    def _time_eager(self, fn, iters: int) -> float:
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier(group=self._cpu_group())
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(iters):                               # aligns the GPUs of the group
+            fn()
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / iters
+
+    def tune(self, sizes=_SIZES, iters: int = 10, with_library: bool | None = None, in_graph: bool = True) -> dict:
+        """Sweep (algorithm × workgroups) per message size; install the winners on every rank.
+
+        Every rank runs the same launches in the same order (the kernels synchronise peer to peer); the table is
+        decided from TP rank 0's timings and broadcast, so the groups' launch shapes can never diverge."""
+        t_begin = time.perf_counter()
+        lib = self.lib
+        max_blocks = int(lib.ar_max_blocks())
+        sizes = [s for s in sizes if s <= self.max_bytes]
+        if with_library is None:
+            with_library = dist.get_backend(self.ctx.group) == "nccl"
+        timer = self._time_graph if in_graph else self._time_eager
+        rows = []
+        for nbytes in sizes:
+            x = torch.ones(nbytes // 2, dtype=torch.bfloat16, device=self.device)
+            out = torch.empty_like(x)
+            cands = []
+            need = max((nbytes // 16 + 511) // 512, 1)
+            block_opts = sorted({min(b, need, max_blocks) for b in (8, 16, 32, 64, 128)})
+            for algo in (1, 2):
+                if algo == 1 and nbytes > (4 << 20):
+                    continue                                 # one-shot moves world × the bytes: hopeless up here
+                if algo == 2 and (self.world <= 2 or nbytes < (32 << 10)):
+                    continue
+                for blocks in block_opts:
+                    us = timer(lambda: lib.ar_all_reduce(self.state, x, out, algo, blocks), iters)
+                    cands.append({"algo": algo, "blocks": blocks, "us": round(us, 2)})
+            row = {"bytes": nbytes, "candidates": cands}
+            if with_library:
+                try:
+                    row["library_us"] = round(self._time_eager(lambda: dist.all_reduce(x, group=self.ctx.group), iters), 2)
+                except Exception as e:                       # the sweep must never take the engine down
+                    row["library_error"] = f"{type(e).__name__}: {e}"
+            rows.append(row)
+        if self.error():
+            raise RuntimeError("custom all-reduce kernel timed out during the launch-shape sweep")
+        rows = self.ctx.broadcast_object(rows, src=0)        # rank 0's clock decides for everyone
+        thr, algos, blocks = [], [], []
+        use_max = self.max_bytes
+        lib_wins_from = None
+        for row in rows:
+            best = min(row["candidates"], key=lambda c: c["us"])
+            row["best"] = best
+            thr.append(row["bytes"])
+            algos.append(best["algo"])
+            blocks.append(best["blocks"])
+            if "library_us" in row:
+                if row["library_us"] < 0.95 * best["us"]:
+                    lib_wins_from = row["bytes"] if lib_wins_from is None else lib_wins_from
+                else:
+                    lib_wins_from = None                     # must win on every larger size too
+        if lib_wins_from is not None:
+            prev = [r["bytes"] for r in rows if r["bytes"] < lib_wins_from]
+            use_max = prev[-1] if prev else 0
+        one_shot_max = max([r["bytes"] for r in rows if r["best"]["algo"] == 1], default=0)
+        lib.ar_set_tuning(self.state, torch.tensor(thr, dtype=torch.int64), torch.tensor(algos, dtype=torch.int32),
+                          torch.tensor(blocks, dtype=torch.int32), int(blocks[-1]) if blocks else 64, int(one_shot_max))
+        self.use_max_bytes = use_max
+        self.tuning = {"world": self.world, "timed_in_graph": in_graph, "rows": rows, "use_custom_up_to_bytes": use_max,
+                       "one_shot_up_to_bytes": one_shot_max, "sweep_seconds": round(time.perf_counter() - t_begin, 2)}
+        dist.barrier(group=self._cpu_group())
+        return self.tuning
 
     def close(self):
         if getattr(self, "state", None):

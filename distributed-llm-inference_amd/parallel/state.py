@@ -8,12 +8,16 @@ this module is the new stack's N1 layer.  Collectives used by the model code:
   through the custom one-/two-shot xGMI kernel when it is initialised (``parallel/custom_all_reduce``),
   everything else through RCCL.
 * ``all_gather``  – vocab-parallel logits.
+* ``all_to_all``  – variable-split row exchange (expert-parallel token dispatch / combine).
 * ``broadcast_object`` / ``broadcast_tensor`` – per-step batch metadata from the driver rank.
+
+Every collective is counted (``ParallelContext.comm``: calls and bytes per kind and per path) so that the
+benchmark can report the all-reduce calls/bytes per step next to its throughput.
 """
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Any, Optional
 
 import torch
@@ -28,6 +32,12 @@ class ParallelContext:
     cpu_group: Optional[Any] = None       # gloo group for object broadcasts
     ep_size: int = 1                      # expert-parallel degree (1 or tp_size)
     custom_ar: Optional[Any] = None       # parallel.custom_all_reduce.CustomAllReduce
+    ep_a2a_min_tokens: int = 0            # MoE steps of at least this many tokens dispatch by all-to-all (0: never)
+    # calls / bytes per collective kind and path since start-up (host-side counts; a hipGraph replay adds the
+    # counts recorded at its capture, see ModelRunner)
+    comm: dict = field(default_factory=lambda: {"ar_custom_calls": 0, "ar_custom_bytes": 0, "ar_lib_calls": 0,
+                                                "ar_lib_bytes": 0, "ag_calls": 0, "ag_bytes": 0, "a2a_calls": 0,
+                                                "a2a_bytes": 0, "bcast_calls": 0, "bcast_bytes": 0})
 
     @property
     def is_driver(self) -> bool:
@@ -37,13 +47,43 @@ class ParallelContext:
     def ep_rank(self) -> int:
         return self.tp_rank if self.ep_size > 1 else 0
 
+    @property
+    def device_backend(self) -> str:
+        if self.tp_size == 1 or self.group is None:
+            return "none"
+        return dist.get_backend(self.group)
+
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         if self.tp_size == 1:
             return x
+        c = self.comm
         if self.custom_ar is not None and self.custom_ar.should_use(x):
+            c["ar_custom_calls"] += 1
+            c["ar_custom_bytes"] += x.numel() * x.element_size()
             return self.custom_ar.all_reduce(x)
+        c["ar_lib_calls"] += 1
+        c["ar_lib_bytes"] += x.numel() * x.element_size()
         dist.all_reduce(x, group=self.group)
         return x
+
+    def all_to_all(self, x: torch.Tensor, out_rows: list, in_rows: list) -> torch.Tensor:
+        """Row exchange: ``x`` is ``[sum(in_rows), …]`` with ``in_rows[r]`` consecutive rows for TP rank r; returns
+        ``[sum(out_rows), …]`` with ``out_rows[r]`` rows received from rank r (``dist.all_to_all_single``: RCCL on
+        GPUs).  The split sizes are host integers — the caller has exchanged the counts beforehand."""
+        if self.tp_size == 1:
+            return x
+        out = torch.empty((int(sum(out_rows)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        self.comm["a2a_calls"] += 1
+        self.comm["a2a_bytes"] += x.numel() * x.element_size()
+        if dist.get_backend(self.group) == "gloo" and x.is_cuda:
+            # gloo has no CUDA all_to_all: stage through the host (single-GPU rehearsal mode only)
+            o = torch.empty(out.shape, dtype=x.dtype)
+            dist.all_to_all_single(o, x.cpu().contiguous(), [int(n) for n in out_rows], [int(n) for n in in_rows],
+                                   group=self.group)
+            out.copy_(o)
+            return out
+        dist.all_to_all_single(out, x.contiguous(), [int(n) for n in out_rows], [int(n) for n in in_rows], group=self.group)
+        return out
 
     def all_gather_last_dim(self, x: torch.Tensor) -> torch.Tensor:
         """[..., n] on every rank → [..., tp·n] ordered by rank."""
@@ -52,6 +92,8 @@ class ParallelContext:
         lead, n = x.shape[:-1], x.shape[-1]
         x2 = x.reshape(-1, n).contiguous()
         rows = x2.shape[0]
+        self.comm["ag_calls"] += 1
+        self.comm["ag_bytes"] += x2.numel() * x2.element_size()
         if self.custom_ar is not None and self.custom_ar.should_use(x2):
             out = self.custom_ar.all_gather(x2)
             return out.permute(1, 0, 2).reshape(*lead, self.tp_size * n)
@@ -59,8 +101,28 @@ class ParallelContext:
         dist.all_gather_into_tensor(out, x2, group=self.group)
         return out.view(self.tp_size, rows, n).permute(1, 0, 2).reshape(*lead, self.tp_size * n)
 
+    def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """``[n, …]`` on every rank → ``[tp·n, …]`` ordered by rank (equal row counts)."""
+        if self.tp_size == 1:
+            return x
+        x = x.contiguous()
+        self.comm["ag_calls"] += 1
+        self.comm["ag_bytes"] += x.numel() * x.element_size()
+        if self.custom_ar is not None and self.custom_ar.should_use(x):
+            return self.custom_ar.all_gather(x).reshape((self.tp_size * x.shape[0],) + tuple(x.shape[1:]))
+        out = torch.empty((self.tp_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x, group=self.group)
+        return out
+
     def broadcast_tensor(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
+        """In place broadcast from TP rank ``src``: the IPC kernel when it is up (no library call on the step path),
+        the device group's broadcast otherwise."""
         if self.tp_size > 1:
+            self.comm["bcast_calls"] += 1
+            self.comm["bcast_bytes"] += x.numel() * x.element_size()
+            if self.custom_ar is not None and self.custom_ar.can_broadcast(x):
+                self.custom_ar.broadcast(x, src)
+                return x
             dist.broadcast(x, src=dist.get_global_rank(self.group, src) if self.group is not None else src,
                            group=self.group)
         return x
@@ -76,6 +138,21 @@ class ParallelContext:
     def barrier(self):
         if self.tp_size > 1:
             dist.barrier(group=self.cpu_group if self.cpu_group is not None else self.group)
+
+    def all_min_int(self, value: int) -> int:
+        """Minimum of a host integer over the TP group (KV-cache sizing: every rank must agree on the page count)."""
+        if self.tp_size == 1:
+            return int(value)
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.cpu_group if self.cpu_group is not None else self.group)
+        return int(t[0])
+
+    def disable_custom_ar(self, why: str = "") -> None:
+        """Permanent switch to the library collectives (a kernel timed out / a self-test failed)."""
+        if self.custom_ar is not None and self.custom_ar.enabled:
+            self.custom_ar.enabled = False
+            print(f"[dli_amd] tp rank {self.tp_rank}: custom all-reduce switched off ({why}); using {self.device_backend}",
+                  flush=True)
 
 
 SINGLE = ParallelContext()
@@ -98,8 +175,15 @@ def init_distributed(backend: str = "auto", device: Optional[torch.device] = Non
 
 
 def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None, with_cpu_group: bool = True,
-                    custom_all_reduce: bool = False, device: Optional[torch.device] = None) -> ParallelContext:
-    """TP group over ``ranks`` (default: the whole world).  Must be called by every rank of the world."""
+                    custom_all_reduce: bool = False, device: Optional[torch.device] = None,
+                    all_groups: Optional[list] = None, device_backend: Optional[str] = None,
+                    ep_a2a_min_tokens: int = 0) -> ParallelContext:
+    """TP group over ``ranks`` (default: the whole world).  Must be called by every rank of the world.
+
+    ``all_groups``: every TP group of the job (list of rank lists, ``ranks`` among them) when the world holds several
+    replicas — ``dist.new_group`` is collective over the WORLD, so each rank creates all groups in the same order and
+    keeps its own.  ``device_backend`` overrides the backend of the device group (``"gloo"`` when the RCCL probe
+    failed: the job still runs, through the custom kernels and host-staged collectives)."""
     if tp_size == 1:
         return ParallelContext()
     assert dist.is_initialized(), "call init_distributed() first"
@@ -107,12 +191,18 @@ def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None
         ranks = list(range(dist.get_world_size()))
     assert len(ranks) == tp_size, f"TP group needs {tp_size} ranks, got {ranks}"
     assert ep_size in (1, tp_size), "expert parallelism is either off or spans the TP group"
-    group = dist.new_group(ranks)
-    cpu_group = None
-    if with_cpu_group and dist.get_backend() != "gloo":
-        cpu_group = dist.new_group(ranks, backend="gloo")
+    group = cpu_group = None
+    world_backend = dist.get_backend()
+    for rs in (all_groups or [ranks]):
+        g = dist.new_group(rs, backend=device_backend) if device_backend else dist.new_group(rs)
+        cg = None
+        if with_cpu_group and (device_backend or world_backend) != "gloo":
+            cg = dist.new_group(rs, backend="gloo")
+        if list(rs) == list(ranks):
+            group, cpu_group = g, cg
+    assert group is not None, f"{ranks} is not one of the groups {all_groups}"
     ctx = ParallelContext(tp_size=tp_size, tp_rank=ranks.index(dist.get_rank()), group=group, cpu_group=cpu_group,
-                          ep_size=ep_size)
+                          ep_size=ep_size, ep_a2a_min_tokens=ep_a2a_min_tokens if ep_size > 1 else 0)
     if custom_all_reduce and device is not None and device.type == "cuda":
         from .custom_all_reduce import CustomAllReduce
         ctx.custom_ar = CustomAllReduce.create(ctx, device)

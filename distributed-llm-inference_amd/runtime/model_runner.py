@@ -55,7 +55,9 @@ class ModelRunner:
         self.local_kv_heads = mcfg.num_kv_heads // self.ctx.tp_size
         self.local_heads = mcfg.num_heads // self.ctx.tp_size
         self.max_blocks_per_seq = (cfg.sched.max_model_len + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
-        self.num_blocks = self._decide_num_blocks()
+        # every rank sizes from its OWN free memory; only the driver's count feeds the block manager, so the group
+        # takes the minimum — a worker with fewer pages than the driver would be handed slots past its cache
+        self.num_blocks = self.ctx.all_min_int(self._decide_num_blocks())
         self.kv_caches = allocate_kv_cache(mcfg.num_layers, self.num_blocks, self.local_kv_heads, mcfg.head_dim,
                                            self.kv_dtype, device)
         self._alloc_buffers()
@@ -66,8 +68,11 @@ class ModelRunner:
         self.graphs: dict[int, tuple] = {}
         self.graph_pool = None
         self.tile_tokens = ops.prefill_tile_tokens(self.local_heads, self.local_kv_heads)
-        self.stats = {"graph_steps": 0, "eager_steps": 0}
+        self.stats = {"graph_steps": 0, "eager_steps": 0, "ar_fallbacks": 0}
+        self.selftest: dict = {}                             # start-up checks of the fast paths → what got disabled
         self._dumped = False
+        self._ar_vote = 0                                    # this rank saw its all-reduce kernel time out
+        self.ctx.barrier()                                   # weights loaded everywhere before the first collective
 
     # ------------------------------------------------------------------ sizing
     def _decide_num_blocks(self) -> int:
@@ -202,13 +207,14 @@ class ModelRunner:
         dv = self.dv
         h = self.model(dv["input"][:T], meta, self.kv_caches)
         if S == 0:
-            return
+            return None
         logits = self.model.compute_logits(h.index_select(0, dv["last"][:S]))
         if _DUMP_LOGITS and self.ctx.is_driver and not torch.cuda.is_current_stream_capturing() and not self._dumped:
             self._dumped = True                              # debug aid: first sampled row of the first eager step
             torch.save(logits[0].float().cpu(), _DUMP_LOGITS)
         ops.sample(logits, dv["temp"][:S], dv["top_p"][:S], dv["top_k"][:S], dv["seeds"][:S], dv["steps"][:S],
                    out=self.d_sampled[:S])
+        return logits
 
     @torch.inference_mode()
     def launch(self, batch, bm):
@@ -235,27 +241,48 @@ class ModelRunner:
         if kind == "host":
             return a
         a.synchronize()                                      # the event recorded behind the D2H copy
+        self._note_ar_error()
         buf, n = b
         return buf.numpy()[:n].copy()
+
+    def _note_ar_error(self):
+        ar = self.ctx.custom_ar
+        if ar is not None and ar.enabled and not self._ar_vote and ar.error_seen:
+            self._ar_vote = 1                                # travels with the next step header; the group switches together
+            print(f"[dli_amd] tp rank {self.ctx.tp_rank}: custom all-reduce timed out waiting for a peer", flush=True)
 
     def execute(self, batch, bm) -> np.ndarray:
         return self.collect(self.launch(batch, bm))
 
     def _broadcast_step(self, header):
-        """Driver → workers: 8-int header over the CPU (gloo) group, packed step buffer over the
-        device group (RCCL broadcast of a few hundred KB)."""
+        """Driver → workers: the step header over the CPU (gloo) group, the packed step buffer over the device
+        path (the IPC broadcast kernel when the custom collectives are up, else the device group's broadcast).
+
+        The header travels as a SUM all-reduce of 9 int64: the driver contributes the 8 header fields, every rank
+        contributes its "my all-reduce kernel timed out" vote in the last slot — so a time-out seen by ANY rank
+        reaches all of them with the next step, and the whole group leaves the custom kernels at the same step."""
         import torch.distributed as dist
         ctx = self.ctx
-        hdr = torch.tensor(header if header is not None else (-1,) * 8, dtype=torch.int64)
+        hdr = torch.zeros(9, dtype=torch.int64)
+        if ctx.is_driver:
+            hdr[:8] = torch.tensor(header, dtype=torch.int64)
+        hdr[8] = self._ar_vote
         g = ctx.cpu_group if ctx.cpu_group is not None else ctx.group
-        dist.broadcast(hdr, src=dist.get_global_rank(g, 0), group=g)
+        dist.all_reduce(hdr, group=g)
         if int(hdr[0]) < 0:
             return None
+        if int(hdr[8]) > 0 and ctx.custom_ar is not None and ctx.custom_ar.enabled:
+            ctx.disable_custom_ar("a rank's kernel gave up waiting for a peer")
+            self.graphs.clear()                              # they hold the custom kernels
+            self.stats["ar_fallbacks"] += 1
+            if dist.get_backend(ctx.group) != "nccl":
+                self.cfg.use_hip_graphs = False              # host-staged collectives cannot be captured
+        head = tuple(int(x) for x in hdr[:8])
         if ctx.is_driver:
-            self._pad_for(tuple(int(x) for x in hdr))
+            self._pad_for(head)
             self._copy_in()
-        dist.broadcast(self.d_buf, src=dist.get_global_rank(ctx.group, 0), group=ctx.group)
-        return tuple(int(x) for x in hdr)
+        ctx.broadcast_tensor(self.d_buf, 0)
+        return head
 
     def worker_step(self) -> bool:
         """Worker-side step (TP rank > 0): wait for the driver's batch and execute it.  Returns False
@@ -266,6 +293,7 @@ class ModelRunner:
         _kind, ev, _ = self.run_staged(header, staged_on_device=True)
         if self._prev_event is not None:                     # stay at most one step ahead of the GPU, like the driver
             self._prev_event.synchronize()
+            self._note_ar_error()
         self._prev_event = ev if _kind == "event" else None
         return True
 
@@ -273,7 +301,9 @@ class ModelRunner:
         if self.ctx.tp_size > 1 and self.ctx.is_driver:
             import torch.distributed as dist
             g = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
-            dist.broadcast(torch.full((8,), -1, dtype=torch.int64), src=dist.get_global_rank(g, 0), group=g)
+            hdr = torch.zeros(9, dtype=torch.int64)
+            hdr[0] = -1
+            dist.all_reduce(hdr, group=g)
 
     def _pad_for(self, header):
         B, bucket = header[0], header[5]
@@ -292,10 +322,20 @@ class ModelRunner:
             # decode rows whose input id was sampled by the step still in flight: take it from the sampler's
             # device output (stream order puts this behind that step and ahead of this step's sampler)
             ops.gather_sampled(self.dv["input"][:nd], self.dv["src"][:nd], self.d_sampled)
+        if bucket and not self.cfg.use_hip_graphs:
+            # the bucket was chosen before graphs were switched off (all-reduce fallback in this very step): run the
+            # padded batch eagerly — padding rows are inert, the split count is the bucket's on every rank
+            B_pad, splits = bucket, self._splits_for_bucket(bucket)
+            self._forward_sample(B_pad, B_pad, self._meta(B_pad, B_pad, B_pad, 0, splits, 0))
+            self.stats["eager_steps"] += 1
+            return self._fetch(B)
         if bucket:
             if bucket not in self.graphs:
                 self.capture_graph(bucket)
-            self.graphs[bucket][0].replay()
+            g = self.graphs[bucket]
+            g[0].replay()
+            for k, v in g[3].items():                        # collectives inside the graph, counted at capture
+                self.ctx.comm[k] += v
             self.stats["graph_steps"] += 1
             return self._fetch(B)
         meta = self._meta(B, T, nd, 0, splits, n_tiles)
@@ -311,6 +351,9 @@ class ModelRunner:
         buf = self.h_sampled[self._fetch_idx]
         if S:
             buf[:S].copy_(self.d_sampled[:S], non_blocking=True)
+        ar = self.ctx.custom_ar
+        if ar is not None and ar.enabled:
+            ar.queue_error_check()                           # 4-byte D2H behind the step: read after its event
         ev = torch.cuda.Event()
         ev.record()
         return ("event", ev, (buf, S))
@@ -350,12 +393,105 @@ class ModelRunner:
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        before = dict(self.ctx.comm)
         with torch.cuda.graph(g, pool=self.graph_pool, stream=stream):
-            self._forward_sample(bucket, bucket, meta)
+            logits = self._forward_sample(bucket, bucket, meta)
+        comm = {k: v - before[k] for k, v in self.ctx.comm.items() if v != before[k]}
         if self.graph_pool is None:
             self.graph_pool = g.pool()
-        self.graphs[bucket] = (g, meta)
+        self.graphs[bucket] = (g, meta, logits, comm)        # `logits`: the graph's own output buffer (self-test reads it)
         return g
+
+    # ------------------------------------------------------------------ start-up self-tests
+    def _stage_synthetic_decode(self, B: int, ctx_len: int = 24):
+        """A deterministic decode batch of ``B`` sequences (one page each) in the static buffers — the same on every
+        TP rank, so no broadcast is needed."""
+        nv = self.nv
+        i = np.arange(B)
+        page = (i % self.num_blocks).astype(np.int32)
+        self.n_bt[:B] = 0
+        self.n_bt[:B, 0] = page
+        self.n_seq_lens[:B] = ctx_len
+        self.n_pos[:B] = ctx_len - 1
+        self.n_slot[:B] = page * KV_BLOCK_SIZE + ctx_len - 1
+        self.n_input[:B] = (i * 7 + 3) % self.cfg.model.vocab_size
+        self.n_qsl[:B + 1] = np.arange(B + 1)
+        nv["last"][:B] = i
+        nv["temp"][:B] = 0.0
+        nv["top_p"][:B] = 1.0
+        nv["top_k"][:B] = 0
+        nv["seeds"][:B] = 1
+        nv["steps"][:B] = 0
+        nv["src"][:B] = -1
+        self._copy_in()
+
+    def _vote(self, ok: bool) -> bool:
+        return bool(self.ctx.all_min_int(1 if ok else 0))
+
+    @torch.inference_mode()
+    def startup_selftest(self) -> dict:
+        """Check the fast paths that change numerics-relevant execution against their plain counterparts, once, on
+        every rank of the group; a path that fails (or raises) is switched off for the life of the engine and the
+        reason is kept in ``self.selftest`` (bench.py prints it).  Covered: a captured decode hipGraph against the
+        same step run eagerly (logit-level), and the GEMM/all-reduce pipeline of ``RowParallelLinear`` against
+        GEMM → all-reduce."""
+        res = self.selftest
+        if not self.on_gpu:
+            return res
+        # --- hipGraph replay vs eager, same staged batch
+        if self.cfg.use_hip_graphs and self.graphs:
+            try:
+                b = min([x for x in self.graphs if x >= 8] or list(self.graphs))
+                self._stage_synthetic_decode(b)
+                meta = self._meta(b, b, b, 0, self._splits_for_bucket(b), 0)
+                le = self._forward_sample(b, b, meta).float().clone()
+                ids_e = self.d_sampled[:b].clone()
+                self.graphs[b][0].replay()
+                lg = self.graphs[b][2].float()
+                diff = float((le - lg).abs().max())
+                scale = float(le.abs().max())
+                same_ids = float((ids_e == self.d_sampled[:b]).float().mean())
+                ok = bool(diff == diff and diff <= 2e-2 * scale + 1e-3)
+                res["graph_vs_eager"] = {"bucket": b, "max_abs_logit_diff": round(diff, 6), "logit_scale": round(scale, 4),
+                                         "greedy_agreement": same_ids}
+            except Exception as e:
+                ok = False
+                res["graph_vs_eager"] = {"error": f"{type(e).__name__}: {e}"}
+            ok = self._vote(ok)
+            res["graph_vs_eager"]["ok"] = ok
+            if not ok:
+                self.cfg.use_hip_graphs = False
+                self.graphs.clear()
+                print(f"[dli_amd] hipGraph decode disabled by the start-up self-test: {res['graph_vs_eager']}", flush=True)
+        # --- overlapped row-parallel linear vs plain
+        if self.ctx.tp_size > 1:
+            from ..models.layers import RowParallelLinear
+            layer = next((m for m in self.model.modules() if isinstance(m, RowParallelLinear) and m.reduce), None)
+            if layer is None or not layer._stream_ordered_backend():
+                res["overlapped_row_parallel"] = {"ok": None, "skipped": f"device backend {self.ctx.device_backend}"}
+                RowParallelLinear.OVERLAP_OK = False
+            else:
+                try:
+                    g = torch.Generator(device=self.device).manual_seed(4321 + self.ctx.tp_rank)
+                    rows = max(RowParallelLinear.OVERLAP_MIN_ROWS, 1024)
+                    x = (torch.randn(rows, layer.weight.data.shape[1], generator=g, device=self.device) * 0.5).to(self.dtype)
+                    want = self.ctx.all_reduce(ops.linear(x, layer.weight.data)).float()
+                    got = layer._forward_overlapped(x, None).float()
+                    torch.cuda.synchronize()
+                    diff = float((want - got).abs().max())
+                    scale = float(want.abs().max())
+                    ok = bool(diff == diff and diff <= 3e-2 * scale + 1e-3)
+                    res["overlapped_row_parallel"] = {"max_abs_diff": round(diff, 6), "scale": round(scale, 4)}
+                except Exception as e:
+                    ok = False
+                    res["overlapped_row_parallel"] = {"error": f"{type(e).__name__}: {e}"}
+                ok = self._vote(ok)
+                res["overlapped_row_parallel"]["ok"] = ok
+                RowParallelLinear.OVERLAP_OK = ok
+                if not ok:
+                    print(f"[dli_amd] GEMM/all-reduce overlap disabled by the start-up self-test: "
+                          f"{res['overlapped_row_parallel']}", flush=True)
+        return res
 
     def capture_all(self, buckets=None):
         """Pre-capture the decode graphs (largest first so that the pool is sized once).  Under TP every

@@ -43,7 +43,8 @@ def _join_group(cfg: EngineConfig, rank: int, world: int, port: int, base_index:
     device = _device_for(cfg, rank, base_index)
     init_distributed(cfg.parallel.backend, device)
     ctx = make_tp_context(world, ep_size=cfg.parallel.ep if cfg.parallel.ep > 1 else 1,
-                          custom_all_reduce=cfg.parallel.custom_all_reduce, device=device)
+                          custom_all_reduce=cfg.parallel.custom_all_reduce, device=device,
+                          ep_a2a_min_tokens=cfg.parallel.ep_a2a_min_tokens)
     return ctx, device
 
 

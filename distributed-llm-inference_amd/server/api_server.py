@@ -146,6 +146,8 @@ class ApiServer:
     @staticmethod
     def _ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, response_text):
         t_first = t_first or t_end
+        if reason == "shed":
+            reason = "error: server overloaded, request shed after waiting too long for admission"
         if reason.startswith("error"):
             return {"model": model, "created_at": _now_iso(), "response": "", "done": True, "done_reason": "error",
                     "error": reason}

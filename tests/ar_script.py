@@ -64,7 +64,18 @@ def main():
         gr.replay()
     torch.cuda.synchronize()
     results["graph"] = float((out.float() - world * (world + 1) / 2).abs().max())
-    results["error_flag"] = ar.error()
+    # broadcast of an int32 buffer from rank 0 (the packed step buffer of a TP step)
+    b = (torch.arange(4096 * 3, dtype=torch.int32, device=dev) * (1 if rank == 0 else -1)).contiguous()
+    ar.broadcast(b, 0)
+    results["broadcast"] = float((b != torch.arange(4096 * 3, dtype=torch.int32, device=dev)).sum())
+    # launch-shape sweep (tiny): every rank must end up with the same table and still reduce correctly
+    tun = ar.tune(sizes=(8 << 10, 128 << 10, 1 << 20), iters=3, with_library=False)
+    assert len(tun["rows"]) == 3 and all("best" in r for r in tun["rows"])
+    x = torch.ones(1 << 19, device=dev, dtype=torch.bfloat16) * (rank + 1)
+    results["after_tune"] = float((ar.all_reduce(x).float() - world * (world + 1) / 2).abs().max())
+    ar.queue_error_check()
+    torch.cuda.synchronize()
+    results["error_flag"] = ar.error() or ar.error_seen
     dist.barrier()
     print("RESULT " + json.dumps(results), flush=True)
     dist.destroy_process_group()

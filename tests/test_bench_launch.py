@@ -1,0 +1,66 @@
+"""bench.py as the driver starts it: `python bench.py --gpus N` WITHOUT a torchrun environment must start its N
+ranks itself (parent never touches a GPU), run DP replicas or TP groups (gloo on CPU here), print ONE JSON line
+from rank 0, and exit non-zero when a rank fails.  Tiny models, seconds to run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--device", "cpu", "--steps", "25", "--warmup", "2", "--ramp-seconds", "2", "--sustained-seconds", "2",
+          "--qps", "8", "--max-num-seqs", "16", "--max-batched-tokens", "256", "--num-kv-blocks", "512"]
+
+
+def run_bench(extra, launcher=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra + COMMON
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_self_launch_dp2():
+    p, lines = run_bench(["--gpus", "2", "--model", "tiny-llama"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["self_launched"] is True
+    assert d["vs_baseline"] is None and d["window_too_short"] is True and "value_sustained" in d
+    assert d["backend"]["control"] == "gloo" and d["device_ids"] == [-1, -1]
+    assert d["requests_finished"] > 0 and d["steps"] == 25
+
+
+def test_self_launch_tp2_reports_collectives():
+    p, lines = run_bench(["--gpus", "2", "--tp", "2", "--model", "tiny-llama"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["config"]["parallelism"] == "tp2" and d["backend"]["device"] == "gloo"
+    # 2 layers × 2 row-parallel all-reduces + the embedding: 5 per step, with their bytes
+    assert d["all_reduce_calls_per_step"] == pytest.approx(5.0) and d["all_reduce_bytes_per_step"] > 0
+    assert d["custom_ar_enabled"] is False and d["rccl_ranks_joined"] == 0
+
+
+def test_torchrun_dp2_x_tp2_ep2():
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                "127.0.0.1", "--master-port", "29641"]
+    p, lines = run_bench(["--gpus", "4", "--tp", "2", "--ep", "2", "--model", "tiny-mixtral", "--ep-a2a-min-tokens", "64"],
+                         launcher=launcher)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["config"]["parallelism"] == "dp2xtp2+ep2" and d["self_launched"] is False
+    assert d["comm_per_step"]["a2a_calls"] > 0          # large steps dispatched by all-to-all
+
+
+def test_failing_rank_fails_the_job():
+    p, lines = run_bench(["--gpus", "2", "--model", "no-such-model"], timeout=120)
+    assert p.returncode != 0 and not lines
+
+
+def test_gpus_must_match_world():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29643")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu"], capture_output=True,
+                       text=True, timeout=60, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "one rank per GPU" in p.stderr

@@ -37,3 +37,18 @@ def test_custom_all_reduce_ipc(world):
         assert res.pop("skew_stress_bad") == 0, res
         for k, err in res.items():
             assert err <= 0.07 * world, (k, err, res)      # bf16 rounding of a sum of `world` unit normals
+
+
+def test_allreduce_microbenchmark_runs(tmp_path):
+    """benchmarks/bench_allreduce.py (the probe bench.py embeds when gpus > 1): 2 ranks sharing the one GPU.  The custom
+    kernels must pass their self-test and the launch-shape sweep must produce a table."""
+    out = tmp_path / "ar.json"
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "benchmarks", "bench_allreduce.py"), "--world", "2",
+                        "--iters", "5", "--out", str(out)], capture_output=True, text=True, timeout=200,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    res = json.loads(out.read_text())
+    assert res["custom_ar_ok"] and res["ranks_share_gpu"]
+    table = res["all_reduce_table"]
+    assert len(table) >= 5 and all(r["one_shot_us"] or r["two_shot_us"] for r in table)
+    assert table[0]["bytes"] == 8 << 10 and table[0]["one_shot_us"] < 200.0

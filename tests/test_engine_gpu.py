@@ -74,6 +74,17 @@ def test_graph_decode_equals_eager_decode():
     assert all(a[:4] == b[:4] for a, b in zip(eager, graph)) and agree > 0.9, (agree, eager, graph)
 
 
+def test_startup_selftest_pins_graph_replay_to_eager_at_logit_level():
+    """The start-up self-test replays a captured decode bucket against the same staged batch run eagerly: same
+    kernels, same inputs → the logits must agree to bf16 noise (and the engine keeps its graphs)."""
+    eng = make(graphs=True)
+    eng.warmup()
+    st = eng.runner.selftest["graph_vs_eager"]
+    assert st["ok"] is True and eng.cfg.use_hip_graphs and eng.runner.graphs
+    assert st["max_abs_logit_diff"] <= 2e-3 * max(st["logit_scale"], 1.0), st
+    assert st["greedy_agreement"] == 1.0
+
+
 def test_chunked_prefill_equals_single_shot_on_gpu():
     p = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
     a = make(graphs=False, chunk=32).generate(None, p, prompt_ids=_prompts(5))

@@ -12,8 +12,8 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def run(model, tp, ep, prompts, pipelined=False):
-    env = dict(os.environ, OMP_NUM_THREADS="2", DLI_TEST_ASYNC="1" if pipelined else "0")
+def run(model, tp, ep, prompts, pipelined=False, ep_a2a=0):
+    env = dict(os.environ, OMP_NUM_THREADS="2", DLI_TEST_ASYNC="1" if pipelined else "0", DLI_TEST_EP_A2A=str(ep_a2a))
     p = subprocess.run([sys.executable, os.path.join(HERE, "tp_script.py"), model, str(tp), str(ep), json.dumps(prompts)],
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -29,8 +29,6 @@ def prompts():
 @pytest.mark.parametrize("model,tp,ep", [("tiny-llama", 2, 1), ("tiny-mixtral", 2, 1), ("tiny-mixtral", 2, 2),
                                          ("tiny-opt", 2, 1), ("tiny-llama", 4, 1)])
 def test_tp_matches_single_rank(model, tp, ep):
-    if model == "tiny-llama" and tp == 4:
-        pytest.skip("tiny-llama has 2 KV heads") if False else None
     want = run(model, 1, 1, prompts())
     if model == "tiny-llama" and tp == 4:
         model_tp = "tiny-llama"
@@ -42,11 +40,21 @@ def test_tp_matches_single_rank(model, tp, ep):
     assert got["sampled"] == want["sampled"]
 
 
+def test_ep_all_to_all_dispatch_matches_single_rank():
+    """Expert parallelism with token-sliced routing + all-to-all dispatch/combine (steps of ≥ 4 tokens here) must
+    reproduce the single-rank tokens; decode steps of < 4 sequences still take the replicated path."""
+    want = run("tiny-mixtral", 1, 1, prompts())
+    got = run("tiny-mixtral", 2, 2, prompts(), ep_a2a=4)
+    assert got["a2a_calls"] > 0, "the all-to-all path never ran"
+    assert got["greedy"] == want["greedy"]
+    assert got["sampled"] == want["sampled"]
+
+
 def test_tp_pipelined_stepping_matches_single_rank():
     """Driver queues step N+1 before step N's ids are known; the workers feed their own sampler output."""
     want = run("tiny-llama", 1, 1, prompts())
     got = run("tiny-llama", 2, 1, prompts(), pipelined=True)
-    assert got == want
+    assert got["greedy"] == want["greedy"] and got["sampled"] == want["sampled"]
 
 
 def test_tp_workers_die_with_the_driver():
@@ -95,3 +103,13 @@ time.sleep(120)
     finally:
         if p.poll() is None:
             p.kill()
+
+
+def test_tp_ranks_agree_on_the_smallest_kv_cache():
+    """Every rank sizes its KV cache from its own free memory; only the driver's count feeds the block manager, so the
+    group must take the minimum — otherwise a worker is handed slots past the end of its cache."""
+    p = subprocess.run([sys.executable, os.path.join(HERE, "tp_minblocks_script.py")], capture_output=True, text=True,
+                       timeout=200, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res == {"runner_blocks": 200, "bm_blocks": 200, "n": 4}
