@@ -199,6 +199,13 @@ def main():
     import torch.distributed as dist
 
     layout = launch.Layout.from_env(args.gpus, args.tp, args.ep)
+    if os.environ.get("DLI_DUMP_STACKS_AFTER"):              # debug aid: where is a hung rank waiting?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DLI_DUMP_STACKS_AFTER"]), repeat=True)
+
+    def note(msg):
+        if layout.rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
     share = os.environ.get("DLI_BENCH_SHARE_GPU") == "1" or os.environ.get("DLI_BENCH_BACKEND") == "gloo"
     on_gpu = args.device == "cuda"
     job = launch.bootstrap(layout, device_kind=args.device, share_gpu=share, custom_all_reduce=not args.no_custom_ar,
@@ -206,6 +213,8 @@ def main():
                            ep_a2a_min_tokens=args.ep_a2a_min_tokens)
     dev, ctx = job.device, job.ctx
     rank, world = layout.rank, layout.world
+    note(f"{world} rank(s) up: device backend {job.comm['device_backend']}, custom all-reduce "
+         f"{job.comm['custom_ar_enabled']}, devices {job.comm['device_ids']}")
 
     from dli_amd.config import (CacheConfig, EngineConfig, ParallelConfig, SchedulerConfig, get_model_config)
     from dli_amd.engine.engine import LLMEngine
@@ -230,10 +239,12 @@ def main():
                        async_scheduling=False if args.sync_steps else None)
     t_load = time.perf_counter()
     eng = LLMEngine(cfg, ctx, dev)
+    note(f"model built in {time.perf_counter() - t_load:.1f} s, {eng.runner.kv_cache_tokens} KV tokens; warming up")
     eng.warmup()
     if on_gpu:
         torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
+    note(f"ready after {t_load:.1f} s ({len(eng.runner.graphs)} decode graphs, self-test {eng.runner.selftest}); replaying")
 
     def sync_drivers():
         if on_gpu:

@@ -149,32 +149,27 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers p, int rank,
   if (!TWO_SHOT) {
     for (int64_t i = tid; i < n_vec; i += stride) dst[i] = reduce_at<W>(p, world, i);
   } else {
-    // slice r = [r*per, min((r+1)*per, n_vec)).  Slice-local index j is handled by the SAME (block, thread) on
-    // every rank in every phase, so the per-block barriers order exactly the data each block consumes.
+    // slice r = [r*per, min((r+1)*per, n_vec)).  Element i is handled by the thread with i ≡ tid (mod stride) on
+    // every rank in every phase — the thread that copied element i into its rank's staging buffer — so the
+    // per-block barriers order exactly the data each block consumes (a block only waits for the SAME block of
+    // its peers).
     const int64_t per = (n_vec + world - 1) / world;
-    const int64_t lo = rank * per;
-    const int64_t cnt = max((int64_t)0, min(per, n_vec - lo));
+    const int64_t lo = rank * per, hi = min(lo + per, n_vec);
     bf16x8* res = reinterpret_cast<bf16x8*>(p.result[rank]);
-    for (int64_t j = tid; j < cnt; j += stride) res[lo + j] = reduce_at<W>(p, world, lo + j);
+    for (int64_t i = lo + ((tid - lo % stride + stride) % stride); i < hi; i += stride) res[i] = reduce_at<W>(p, world, i);
     mesh_barrier<1>(p, rank, world, flag);
-    for (int64_t j = tid; j < per; j += stride) {
-      if constexpr (W > 0) {
-        bf16x8 v[W];
+    constexpr int U = 4;                                    // loads in flight per thread in the gather
+    for (int64_t i0 = tid; i0 < n_vec; i0 += stride * U) {
+      bf16x8 v[U];
 #pragma unroll
-        for (int r = 0; r < W; ++r) {
-          const int64_t i = r * per + j;
-          if (i < n_vec) v[r] = reinterpret_cast<const bf16x8*>(p.result[r])[i];
-        }
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < n_vec) v[u] = reinterpret_cast<const bf16x8*>(p.result[i / per])[i];
+      }
 #pragma unroll
-        for (int r = 0; r < W; ++r) {
-          const int64_t i = r * per + j;
-          if (i < n_vec) dst[i] = v[r];
-        }
-      } else {
-        for (int r = 0; r < world; ++r) {
-          const int64_t i = r * per + j;
-          if (i < n_vec) dst[i] = reinterpret_cast<const bf16x8*>(p.result[r])[i];
-        }
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i < n_vec) dst[i] = v[u];
       }
     }
   }

@@ -201,7 +201,7 @@ class CustomAllReduce:
             need = max((nbytes // 16 + 511) // 512, 1)
             block_opts = sorted({min(b, need, max_blocks) for b in (8, 16, 32, 64, 128)})
             for algo in (1, 2):
-                if algo == 1 and nbytes > (4 << 20):
+                if algo == 1 and nbytes > (4 << 20) and self.world > 2:
                     continue                                 # one-shot moves world × the bytes: hopeless up here
                 if algo == 2 and (self.world <= 2 or nbytes < (32 << 10)):
                     continue

@@ -499,11 +499,21 @@ class ModelRunner:
         if not (self.on_gpu and self.cfg.use_hip_graphs):
             return 0
         todo = [b for b in (buckets or self.cfg.graph_batch_sizes) if b <= self.cfg.sched.max_num_seqs]
-        for bucket in sorted(todo, reverse=True):
-            if bucket in self.graphs:
-                continue
-            self._pad_decode(0, bucket)
-            self._copy_in()
-            self.capture_graph(bucket)
-        torch.cuda.synchronize()
+        err = None
+        try:
+            for bucket in sorted(todo, reverse=True):
+                if bucket in self.graphs:
+                    continue
+                self._pad_decode(0, bucket)
+                self._copy_in()
+                self.capture_graph(bucket)
+            torch.cuda.synchronize()
+        except Exception as e:                               # e.g. a collective that cannot be captured on this backend
+            err = f"{type(e).__name__}: {e}"
+        if not self._vote(err is None):                      # all ranks keep their graphs, or none does
+            self.selftest["graph_capture"] = {"ok": False, "error": err or "failed on another rank"}
+            print(f"[dli_amd] hipGraph capture failed ({self.selftest['graph_capture']['error']}): decode steps run eagerly",
+                  flush=True)
+            self.cfg.use_hip_graphs = False
+            self.graphs.clear()
         return len(self.graphs)
