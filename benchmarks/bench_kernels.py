@@ -215,6 +215,53 @@ def bench_moe(quick):
         report("fused_moe", t, flops=2 * rows * 3 * I * H, bytes_=hit * 3 * I * H * 2, T=T, local_experts=El, experts_hit=hit)
 
 
+def bench_gemm256(quick):
+    """Large-M A/B, GPU time inside hipGraphs, random data, weights rotated past the infinity cache:
+    (a) gate/up projection: library GEMM + silu_and_mul kernel  vs  the 256² tile kernel with the SwiGLU epilogue;
+    (b) plain projections: library GEMM vs the 256² tile kernel;
+    (c) MoE block: 128-row tiles (moe.hip) vs 256-row tiles (gemm256.hip)."""
+    import torch.nn.functional as F
+    lib = ops.hip()
+    shapes = [("8b_gate_up", 28672, 4096, True), ("70b_tp8_gate_up", 7168, 8192, True), ("8b_qkv", 6144, 4096, False),
+              ("8b_down", 4096, 14336, False), ("70b_tp8_down", 8192, 3584, False)]
+    for name, N, K, swiglu in (shapes[:2] if quick else shapes):
+        if not swiglu and N % 256:
+            continue
+        copies = max(2, -(-(600 << 20) // (N * K * 2)))
+        ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(copies)]
+        for M in ((4096,) if quick else (512, 1024, 2048, 4096, 8192)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            state = {"i": 0}
+
+            def call(fn):
+                def run():
+                    state["i"] = (state["i"] + 1) % copies
+                    return fn(x, ws[state["i"]])
+                return run
+            if swiglu:
+                t_lib = timeit_graph(call(lambda a, w: ops.silu_and_mul(F.linear(a, w))), 2 * copies)
+                t_gemm = timeit_graph(call(lambda a, w: F.linear(a, w)), 2 * copies)
+            else:
+                t_lib = t_gemm = timeit_graph(call(lambda a, w: F.linear(a, w)), 2 * copies)
+            t_new = timeit_graph(call(lambda a, w: lib.dense_gemm256(a, w, swiglu)), 2 * copies)
+            fl = 2.0 * M * N * K
+            report("gemm256(" + name + (",swiglu" if swiglu else "") + ")", t_new, flops=fl, M=M, N=N, K=K,
+                   library_us=round(t_lib * 1e6, 1), library_gemm_only_us=round(t_gemm * 1e6, 1),
+                   library_TFLOPs=round(fl / t_gemm / 1e12, 1), speedup_vs_library_path=round(t_lib / t_new, 3))
+        del ws
+    H, I, E = 4096, 14336, 8
+    for T, El in ([(4096, 8)] if quick else [(1024, 8), (2048, 8), (4096, 8), (8192, 8), (4096, 1)]):
+        x = torch.randn(T, H, device=DEV).bfloat16()
+        logits = torch.randn(T, E, device=DEV).bfloat16()
+        w13 = (torch.randn(El, 2 * I, H, device=DEV) * 0.02).bfloat16()
+        w2 = (torch.randn(El, H, I, device=DEV) * 0.02).bfloat16()
+        rows = T * 2 * El / E
+        ts = {tile: timeit_graph(lambda: lib.fused_moe(x, logits, w13, w2, 2, 0, tile), 6) for tile in (128, 256)}
+        report("fused_moe(tile 256 vs 128)", ts[256], flops=2 * rows * 3 * I * H, T=T, local_experts=El,
+               tile128_us=round(ts[128] * 1e6, 1), tile128_TFLOPs=round(2 * rows * 3 * I * H / ts[128] / 1e12, 1),
+               speedup=round(ts[128] / ts[256], 3))
+
+
 def bench_linear(quick):
     """Decode-sized linear layers: the weight-streaming kernel against the library GEMM (hipBLASLt via torch).
     Weights rotate through ≥ 1 GB of copies so that no call finds its matrix in the 256 MB infinity cache."""
@@ -278,6 +325,8 @@ def main():
         bench_sampler(a.quick)
     if run("moe"):
         bench_moe(a.quick)
+    if run("gemm256"):
+        bench_gemm256(a.quick)
     if run("linear"):
         bench_linear(a.quick)
 

@@ -1,0 +1,334 @@
+// 256×256×64 bf16 GEMM tile for gfx950: the large-M path of the MoE grouped GEMM (K8) and of the dense gate/up
+// projection with the SwiGLU epilogue (K3 folded into K11).   C[rows, n] = A[rows, :] · W[n, :]ᵀ
+//
+// Why this shape (cdna guide §5, MI355X_MICROARCH §LDS / §Two waves per SIMD):
+//   * 8 waves as 2 (M) × 4 (N); a wave owns 128 × 64 of the output = 8 × 4 accumulators of v_mfma_f32_16x16x32_bf16
+//     (the shape that holds the higher clock on random data).  Per K-step of 64 a wave reads 24 fragments
+//     (ds_read_b128) for 64 MFMAs — half the LDS bytes per MFMA of the 64×64-per-wave tile in moe.hip, whose loop
+//     was LDS-bound at 35 % MFMA-busy.
+//   * both operands stream global → LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  The
+//     LDS image is lane-linear, so the bank swizzle sits on the SOURCE address (slot p of row r receives global
+//     chunk p ^ (r & 7)) and on the read — never on the destination (guide rule 21).  With that swizzle the four
+//     16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots: conflict-free.
+//   * two K-step buffers of 64 KB (all LDS in ONE array, laid out A0 A1 B0 B1 so that every fragment read is a base
+//     register + a 16-bit immediate).  A K-step is four quadrant phases of 16 MFMAs.
+//   * PING-PONG between the two waves of a SIMD.  Every phase is a LOAD segment (the quadrant's ds_read_b128s + one
+//     128-row half-tile of LDS-DMA = 2 instructions per wave) and an MFMA segment, each closed by a raw s_barrier.
+//     Waves 4–7 enter the loop one barrier late, so on every SIMD one wave runs its 16 MFMAs while its partner
+//     issues reads and DMA: the matrix pipe never waits for an address unit, and neither wave needs double-buffered
+//     fragments (64 operand VGPRs + 128 accumulators).  (v1 of this kernel kept all 8 waves in lockstep with one
+//     barrier per K-step: every wave issued its 8 DMAs behind the same barrier and the MFMA pipe idled for
+//     ≈ 40 % of the step — profiles/gemm256_r2b_v1_one_barrier_per_kstep.jsonl.)
+//   * DMA schedule: a half-tile is re-filled for the step two ahead right after BOTH wave groups have read it —
+//     7 phases before its first read.  Every MFMA segment ends with s_waitcnt vmcnt(8): at most the four youngest half-tiles of a
+//     wave are in flight, older ones have landed, and the two barriers that follow make that true for both groups
+//     before anyone reads them (guide: "read a staged buffer one phase AFTER the wait that retires it", one barrier
+//     more for staggered groups).  Never vmcnt(0) in the steady state; the last two K-steps drain.
+//     Every LOAD segment ends with lgkmcnt(0) BEFORE its barrier, so "passed the barrier" ⇒ "my reads are done":
+//     that is what makes the re-fill of a half-tile safe.
+//   * the accumulator is D[weight column][token row] (operands swapped), so a lane holds 4 consecutive output
+//     columns of one row: 8-byte row-contiguous stores, and the SwiGLU pair (gate column, up column) of a row
+//     lives in the same lane.
+//   * block → tile mapping: XCD x runs the x-th eighth of the tile order (8-column groups, row tile, column).
+#include "common.h"
+#include "kernels.h"
+
+namespace dli {
+
+namespace g256 {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int TILE_BYTES = TM * TK * 2;        // one operand tile of one K-step: 32 KB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+
+enum { EPI_SWIGLU = 0, EPI_SCATTER = 1, EPI_SCATTER_SPLITK = 2, EPI_PLAIN = 3 };
+
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+using gptr_t = const __attribute__((address_space(1))) void*;
+using lptr_t = __attribute__((address_space(3))) void*;
+
+// GROUPED: rows come from the MoE alignment (sorted_ids / tile_expert / meta); otherwise rows 0..M-1 of A, one "expert".
+template <int EPI, bool GROUPED>
+__global__ __launch_bounds__(512) void gemm256_kernel(
+    const uint16_t* __restrict__ A, int64_t a_stride, const uint16_t* __restrict__ W, int64_t w_expert_stride,
+    const int* __restrict__ sorted_ids, const int* __restrict__ tile_expert, const int* __restrict__ meta,
+    const float* __restrict__ topk_w, int top_k, void* __restrict__ out_, int64_t out_stride, int M, int K, int N_half,
+    int n_col_blocks, int k_splits, int64_t slab_elems) {
+  uint16_t* out = reinterpret_cast<uint16_t*>(out_);
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
+
+  // ---- block → (row tile, column block).  The hardware deals workgroups round-robin over the 8 XCDs (id % 8), each
+  // with a private 4 MB L2.  Tiles are put in the linear order (group of 8 column blocks, row tile, column in group)
+  // and XCD x runs the x-th eighth of that order: the ≈ 32 blocks resident on an XCD at a time are 4 row tiles × 8
+  // column blocks — each operand K-slice is fetched into that L2 once and used 4–8 times — and the eighths differ by
+  // at most one tile (whole super-tiles per XCD left XCDs 4–7 idle for the last 1/8 of a 28-super-tile launch).
+  const int n_tiles = GROUPED ? meta[0] : (M + TM - 1) / TM;
+  const int n_virtual = n_col_blocks * k_splits;             // split-K slices are extra "columns" (slowest index)
+  const int total = n_tiles * n_virtual;
+  const int per_xcd = (total + 7) >> 3;
+  const int in_xcd = blockIdx.x >> 3;
+  const int lin = (blockIdx.x & 7) * per_xcd + in_xcd;
+  if (in_xcd >= per_xcd || lin >= total) return;
+  constexpr int GW = 8;
+  const int grp = lin / (GW * n_tiles), within = lin - grp * (GW * n_tiles);
+  const int gw = min(GW, n_virtual - grp * GW);              // the last group may be narrower
+  const int tile = within / gw;
+  const int col_virtual = grp * GW + (within - tile * gw);
+  const int split = col_virtual / n_col_blocks;
+  const int col_block = col_virtual - split * n_col_blocks;
+  const int e = GROUPED ? tile_expert[tile] : 0;
+  const uint16_t* We = W + (int64_t)e * w_expert_stride;
+  const int n0 = col_block * (EPI == EPI_SWIGLU ? TN / 2 : TN);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int col = lane & 15, g = lane >> 4;
+
+  // ---- LDS-DMA sources.  A half-tile (a0, a1: 64 rows of each wave row; b0, b1: 32 rows of each wave column) is 128
+  // rows = 16 pieces of 8 rows × 128 B = 1 KiB; wave w fills pieces 2w and 2w+1 of every half-tile.  Lane → row
+  // lane/8 of the piece, slot lane%8, which receives global chunk slot ^ (row & 7) (swizzle on the source side).
+  uint32_t a_src[2][2], b_src[2][2];                         // [half][piece j] byte offset of this lane's 16 bytes at k = 0
+  int a_dst[2][2], b_dst[2][2];                              // wave-uniform LDS byte offset of the piece inside its tile
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int lr0 = (2 * wave + jj) * 8;                    // first logical row of the piece inside the half-tile
+      const int ar0 = (lr0 >> 6) * 128 + h * 64 + (lr0 & 63), br0 = (lr0 >> 5) * 64 + h * 32 + (lr0 & 31);
+      a_dst[h][jj] = ar0 * 128;
+      b_dst[h][jj] = br0 * 128;
+      const int ar = ar0 + (lane >> 3), br = br0 + (lane >> 3);
+      int64_t arow;
+      if (GROUPED && EPI == EPI_SWIGLU) {
+        const int sid = sorted_ids[tile * TM + ar];
+        arow = sid >= 0 ? sid / top_k : 0;                   // padding rows read token 0 (discarded later)
+      } else if (GROUPED) {
+        arow = (int64_t)tile * TM + ar;
+      } else {
+        arow = min(tile * TM + ar, M - 1);                   // rows past M repeat the last row (never stored)
+      }
+      a_src[h][jj] = (uint32_t)((arow * a_stride + (((lane & 7) ^ (ar & 7)) * 8)) * 2);
+      int wrow;
+      if (EPI == EPI_SWIGLU) {
+        const int w_ = br >> 6, within = br & 63;             // wave column, position inside its 32 gate + 32 up rows
+        wrow = (within < 32 ? 0 : N_half) + n0 + w_ * 32 + (within & 31);
+      } else {
+        wrow = n0 + br;
+      }
+      b_src[h][jj] = (uint32_t)(((int64_t)wrow * K + (((lane & 7) ^ (br & 7)) * 8)) * 2);
+    }
+  const char* Ab = reinterpret_cast<const char*>(A);
+  const char* Wb = reinterpret_cast<const char*>(We);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_total = K / TK;
+  const int kt0 = (int)((int64_t)nk_total * split / k_splits);
+  const int nk = (int)((int64_t)nk_total * (split + 1) / k_splits) - kt0;      // K-steps of this block
+
+  // one half-tile (2 DMA instructions per wave) of K-step kt_ into buffer buf_
+#define G256_STAGE_A(kt_, buf_, h_)                                                                                  \
+  _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) __builtin_amdgcn_global_load_lds(                                  \
+      (gptr_t)(Ab + a_src[h_][jj] + ((kt_) + kt0) * (TK * 2)), (lptr_t)(lds + (buf_) * TILE_BYTES + a_dst[h_][jj]), 16, 0, 0);
+#define G256_STAGE_B(kt_, buf_, h_)                                                                                  \
+  _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) __builtin_amdgcn_global_load_lds(                                  \
+      (gptr_t)(Wb + b_src[h_][jj] + ((kt_) + kt0) * (TK * 2)), (lptr_t)(lds + STAGE_BYTES + (buf_) * TILE_BYTES + b_dst[h_][jj]), 16, 0, 0);
+  // fragment reads: A rows wr·128 + m·16 + col, B rows wc·64 + n·16 + col; chunk ks·4 + g of the 64-wide K-step
+  // (row offsets that are multiples of 8 rows leave the swizzle term alone: two base addresses per operand — one per
+  //  32-wide k half — and compile-time immediates for everything else)
+  const char* a_rd[2] = {lds + lds_off(wr * 128 + col, g), lds + lds_off(wr * 128 + col, 4 + g)};
+  const char* b_rd[2] = {lds + STAGE_BYTES + lds_off(wc * 64 + col, g), lds + STAGE_BYTES + lds_off(wc * 64 + col, 4 + g)};
+#define G256_RD_A(dst_, buf_, half_)                                                                                 \
+  _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
+      dst_[m][ks] = *reinterpret_cast<const bf16x8*>(a_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 64 + m * 16) * 128);
+#define G256_RD_B(dst_, buf_, half_)                                                                                 \
+  _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
+      dst_[n][ks] = *reinterpret_cast<const bf16x8*>(b_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 32 + n * 16) * 128);
+  // end of a LOAD segment: my reads are complete before I pass the barrier (→ the half-tile may be re-filled)
+#define G256_END_LOAD()                                                                                              \
+  {                                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+  // MFMA segment: 16 MFMAs of one quadrant (k-step outermost: 8 independent accumulators between two uses of one),
+  // then the counted DMA wait and the barrier
+#define G256_MMA(fa_, fb_, mh_, nh_, drain_)                                                                         \
+  {                                                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                    \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                \
+            acc[(mh_) * 4 + m][(nh_) * 2 + n] = mfma16(fb_[n][ks], fa_[m][ks], acc[(mh_) * 4 + m][(nh_) * 2 + n]);    \
+    __builtin_amdgcn_s_setprio(0);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (drain_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                            \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+    asm volatile("" ::: "memory");                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+  // One K-step from buffer buf_ (= t & 1 = f_, the B half the step starts with).  Quadrants (a0,bf) (a0,bo) (a1,bo)
+  // (a1,bf): the last one leaves the registers of bo free, and the NEXT step starts with bo — its first B fragments
+  // are read in this step's last LOAD segment, which keeps the segments at 8 / 4 / 8 / 4 reads + 2 DMAs each.
+  // DMA of step t+2 into this buffer, each half-tile right after both wave groups have read it: L0: bf (read one phase
+  // before the step began), L1: a0, L2: bo, L3: a1 — 7 phases ahead of its first read.
+  // (full_: a steady-state step, two more steps follow — no conditions at all in its instruction stream)
+#define G256_STEP(t_, buf_, full_)                                                                                   \
+  {                                                                                                                  \
+    constexpr int f_ = (buf_), o_ = 1 - (buf_);                                                                      \
+    const bool drain_ = !(full_) && (t_) + 2 >= nk;           /* nothing more will be issued: counted waits would lie */ \
+    const bool more_ = (full_) || (t_) + 2 < nk;                                                                     \
+    G256_RD_A(fa, buf_, 0);                                                                                          \
+    if (more_) G256_STAGE_B((t_) + 2, buf_, f_);                                                                     \
+    G256_END_LOAD();                                                                                                 \
+    G256_MMA(fa, fb[f_], 0, f_, drain_);                                                                             \
+    G256_RD_B(fb[o_], buf_, o_);                                                                                     \
+    if (more_) G256_STAGE_A((t_) + 2, buf_, 0);                                                                      \
+    G256_END_LOAD();                                                                                                 \
+    G256_MMA(fa, fb[o_], 0, o_, drain_);                                                                             \
+    G256_RD_A(fa, buf_, 1);                                                                                          \
+    if (more_) G256_STAGE_B((t_) + 2, buf_, o_);                                                                     \
+    G256_END_LOAD();                                                                                                 \
+    G256_MMA(fa, fb[o_], 1, o_, drain_);                                                                             \
+    if ((full_) || (t_) + 1 < nk) G256_RD_B(fb[o_], (buf_) ^ 1, o_);                                                 \
+    if (more_) G256_STAGE_A((t_) + 2, buf_, 1);                                                                      \
+    G256_END_LOAD();                                                                                                 \
+    G256_MMA(fa, fb[f_], 1, f_, drain_);                                                                             \
+  }
+
+  bf16x8 fa[4][2], fb[2][2][2];                              // a0 or a1 (64 rows); fb[h]: b half h (32 weight rows)
+
+  // prologue: steps 0 and 1 completely (the loop issues from step 2 on), then the first B fragments of step 0
+  G256_STAGE_B(0, 0, 0);
+  G256_STAGE_A(0, 0, 0);
+  G256_STAGE_B(0, 0, 1);
+  G256_STAGE_A(0, 0, 1);
+  if (nk > 1) {
+    G256_STAGE_B(1, 1, 1);
+    G256_STAGE_A(1, 1, 0);
+    G256_STAGE_B(1, 1, 0);
+    G256_STAGE_A(1, 1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // step 0 landed, step 1 still in flight
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  G256_RD_B(fb[0], 0, 0);
+  if (wr == 1) {                                               // the stagger: waves 4–7 run one segment behind
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  int t = 0;
+  for (; t + 3 < nk; t += 2) {                                 // steady state: both steps have two more behind them
+    G256_STEP(t, 0, true);
+    G256_STEP(t + 1, 1, true);
+  }
+  if (t < nk) G256_STEP(t, 0, false);                          // the last (up to three) steps: guarded issue, draining waits
+  if (t + 1 < nk) G256_STEP(t + 1, 1, false);
+  if (t + 2 < nk) G256_STEP(t + 2, 0, false);
+  if (wr == 0) __builtin_amdgcn_s_barrier();                   // pairs with the extra barrier of waves 4–7
+#undef G256_STAGE_A
+#undef G256_STAGE_B
+#undef G256_RD_A
+#undef G256_RD_B
+#undef G256_END_LOAD
+#undef G256_MMA
+#undef G256_STEP
+
+  // ---- epilogue.  acc[m][n][r]: row = wr·128 + m·16 + col, output column = wc·64 + n·16 + 4g + r
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int prow = tile * TM + wr * 128 + m * 16 + col;
+    const int sid = GROUPED ? sorted_ids[prow] : (prow < M ? prow : -1);
+    if (EPI == EPI_SWIGLU) {
+      // wave columns: n = 0,1 gate (32 columns), n = 2,3 the matching up columns
+      if (GROUPED || sid >= 0) {
+        uint16_t* dst = out + (int64_t)prow * out_stride + n0 + wc * 32 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gate = acc[m][n][r], up = acc[m][n + 2][r];
+            o[r] = (short)f2bf(gate * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * gate)) * up);
+          }
+          *reinterpret_cast<bf16x4*>(dst + n * 16) = o;        // grouped padding rows hold finite junk, never read back
+        }
+      }
+    } else if (EPI == EPI_SCATTER_SPLITK) {
+      if (sid >= 0) {
+        const float w = topk_w[sid];
+        float* dst = reinterpret_cast<float*>(out_) + split * slab_elems + (int64_t)sid * out_stride + n0 + wc * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = acc[m][n][r] * w;
+          *reinterpret_cast<f32x4*>(dst + n * 16) = o;
+        }
+      }
+    } else if (sid >= 0) {
+      const float w = EPI == EPI_SCATTER ? topk_w[sid] : 1.f;
+      uint16_t* dst = out + (int64_t)sid * out_stride + n0 + wc * 64 + 4 * g;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (short)f2bf(acc[m][n][r] * w);
+        *reinterpret_cast<bf16x4*>(dst + n * 16) = o;
+      }
+    }
+  }
+}
+
+}  // namespace g256
+
+// epilogue: 0 SwiGLU, 1 scatter (MoE down), 2 scatter split-K (fp32 slabs).  Same contract as launch_grouped_gemm,
+// 256-row tiles (moe_align must have padded the expert segments to 256).
+void launch_grouped_gemm256(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
+                            const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
+                            void* out, int64_t out_stride, int K, int N_out, int max_tiles, int k_splits, int64_t slab_elems,
+                            hipStream_t stream) {
+  using namespace g256;
+  if (max_tiles == 0) return;
+  const int n_col_blocks = N_out / (epilogue == EPI_SWIGLU ? TN / 2 : TN);
+  const int n_virtual = n_col_blocks * k_splits;
+  dim3 grid((max_tiles * n_virtual + 7) / 8 * 8);                            // surplus blocks exit on meta[0]
+#define G256_GO(EPI)                                                                                                       \
+  hipLaunchKernelGGL((gemm256_kernel<EPI, true>), grid, dim3(512), 0, stream, (const uint16_t*)A, a_stride, (const uint16_t*)W, \
+                     w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, out_stride, 0, K, N_out, n_col_blocks, \
+                     k_splits, slab_elems)
+  if (epilogue == EPI_SWIGLU) G256_GO(EPI_SWIGLU);
+  else if (epilogue == EPI_SCATTER) G256_GO(EPI_SCATTER);
+  else G256_GO(EPI_SCATTER_SPLITK);
+#undef G256_GO
+}
+
+// Dense y = x · Wᵀ (swiglu = false: W [N, K] → y [M, N]) or y = silu(x · W_gateᵀ) ⊙ (x · W_upᵀ)
+// (swiglu = true: W = [W_gate; W_up] of 2·N_out rows → y [M, N_out]).  K % 64 == 0, N_out % 256 (128 with swiglu) == 0.
+void launch_dense_gemm256(bool swiglu, const void* x, int64_t x_stride, const void* W, void* out, int64_t out_stride, int M,
+                          int K, int N_out, hipStream_t stream) {
+  using namespace g256;
+  if (M == 0) return;
+  const int n_tiles = (M + TM - 1) / TM;
+  const int n_col_blocks = N_out / (swiglu ? TN / 2 : TN);
+  dim3 grid((n_tiles * n_col_blocks + 7) / 8 * 8);
+  if (swiglu)
+    hipLaunchKernelGGL((gemm256_kernel<EPI_SWIGLU, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
+                       (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, out, out_stride, M, K, N_out,
+                       n_col_blocks, 1, (int64_t)0);
+  else
+    hipLaunchKernelGGL((gemm256_kernel<EPI_PLAIN, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
+                       (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, out, out_stride, M, K, N_out,
+                       n_col_blocks, 1, (int64_t)0);
+}
+
+}  // namespace dli

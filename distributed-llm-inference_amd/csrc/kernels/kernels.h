@@ -39,11 +39,18 @@ void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int
 // mixture of experts (moe.hip)
 void launch_moe_route(const void* logits, int T, int E, int K, int* ids, float* weights, hipStream_t stream);
 void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int* sorted_ids, int* tile_expert, int* meta,
-                      int capacity_rows, hipStream_t stream);
+                      int capacity_rows, int tile_rows, hipStream_t stream);
 void launch_grouped_gemm(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
                          const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
                          void* out, int64_t out_stride, int K, int N_out, int max_tiles, int k_splits, int64_t slab_elems,
                          hipStream_t stream);
+// 256×256×64 tile (gemm256.hip): large-M grouped GEMM and dense GEMM with optional SwiGLU epilogue
+void launch_grouped_gemm256(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,
+                            const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
+                            void* out, int64_t out_stride, int K, int N_out, int max_tiles, int k_splits, int64_t slab_elems,
+                            hipStream_t stream);
+void launch_dense_gemm256(bool swiglu, const void* x, int64_t x_stride, const void* W, void* out, int64_t out_stride, int M,
+                          int K, int N_out, hipStream_t stream);
 void launch_moe_sum(const void* y, bool y_fp32, int n_slabs, int64_t slab_elems, const int* ids, int expert_offset, int E_local,
                     int top_k, int T, int H, void* out, hipStream_t stream);
 

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void moe_route_kernel(const uint16_t* __restri
 // meta[0] = number of row tiles, meta[1] = padded row count
 __global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__ ids, int n, int expert_offset, int E_local,
                                                          int* __restrict__ sorted_ids, int* __restrict__ tile_expert,
-                                                         int* __restrict__ meta, int capacity_rows) {
+                                                         int* __restrict__ meta, int capacity_rows, int tile_rows) {
+  const int BM = tile_rows;                               // row tile of the GEMM that consumes the alignment (128 or 256)
   __shared__ int cnt[MOE_MAX_E], off[MOE_MAX_E + 1], pos[MOE_MAX_E];
   for (int e = threadIdx.x; e < MOE_MAX_E; e += blockDim.x) { cnt[e] = 0; pos[e] = 0; }
   __syncthreads();
@@ -292,9 +293,9 @@ void launch_moe_route(const void* logits, int T, int E, int K, int* ids, float* 
 }
 
 void launch_moe_align(const int* ids, int n, int expert_offset, int E_local, int* sorted_ids, int* tile_expert, int* meta,
-                      int capacity_rows, hipStream_t stream) {
+                      int capacity_rows, int tile_rows, hipStream_t stream) {
   hipLaunchKernelGGL(moe_align_kernel, dim3(1), dim3(1024), 0, stream, ids, n, expert_offset, E_local, sorted_ids, tile_expert,
-                     meta, capacity_rows);
+                     meta, capacity_rows, tile_rows);
 }
 
 void launch_grouped_gemm(int epilogue, const void* A, int64_t a_stride, const void* W, int64_t w_expert_stride,

@@ -195,13 +195,34 @@ void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
                              cur_stream(input));
 }
 
+// y = x · Wᵀ on the 256×256×64 tile kernel (gemm256.hip); swiglu: W = [gate; up] rows, y = silu(x·gateᵀ) ⊙ (x·upᵀ)
+Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu) {
+  check_bf16_rows(x, "x");
+  const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
+  TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
+              "dense_gemm256: weight must be a contiguous bf16 [N, K] GPU tensor with K = ", K);
+  const int64_t n_out = swiglu ? N / 2 : N;
+  TORCH_CHECK(K % 64 == 0 && n_out % (swiglu ? 128 : 256) == 0 && N % 2 == 0, "dense_gemm256: unsupported shape N=", N, " K=", K);
+  TORCH_CHECK(M >= 1 && M * x.stride(0) * 2 < (int64_t(1) << 32) && N * K * 2 < (int64_t(1) << 32), "dense_gemm256: operand too large");
+  Tensor out = at::empty({M, n_out}, x.options());
+  dli::launch_dense_gemm256(swiglu, x.data_ptr(), x.stride(0), w.data_ptr(), out.data_ptr(), n_out, (int)M, (int)K, (int)n_out,
+                            cur_stream(x));
+  return out;
+}
+
+// row tile of the grouped GEMM: 256 from this many routed rows per local expert on (DLI_MOE_TILE=128|256 forces one)
+const int64_t g_moe_tile_force = std::getenv("DLI_MOE_TILE") ? std::atoll(std::getenv("DLI_MOE_TILE")) : 0;
+const int64_t g_moe_tile256_min_rows = std::getenv("DLI_MOE_TILE256_MIN_ROWS") ? std::atoll(std::getenv("DLI_MOE_TILE256_MIN_ROWS")) : 384;
+
+const int64_t g_moe_splitk_min_blocks256 = std::getenv("DLI_MOE_SPLITK_MIN_BLOCKS256") ? std::atoll(std::getenv("DLI_MOE_SPLITK_MIN_BLOCKS256")) : 512;
+
 // largest batch routed to the weight-streaming MoE path; DLI_NO_SKINNY_MOE / DLI_SKINNY_MOE_MAX_T: A-B measurements
 const int64_t g_moe_skinny_max_t = std::getenv("DLI_NO_SKINNY_MOE") ? 0
                                    : std::getenv("DLI_SKINNY_MOE_MAX_T") ? std::atoll(std::getenv("DLI_SKINNY_MOE_MAX_T")) : 32;
 
 // ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
-                 int64_t expert_offset) {
+                 int64_t expert_offset, int64_t tile_rows) {
   check_bf16_rows(x, "x");
   TORCH_CHECK(router_logits.is_cuda() && router_logits.scalar_type() == at::kBFloat16 && router_logits.dim() == 2,
               "router_logits must be a 2-D bfloat16 GPU tensor");
@@ -214,12 +235,18 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   auto stream = cur_stream(x);
   auto i32 = x.options().dtype(at::kInt);
   const int64_t n = T * top_k;
-  const int64_t capacity = (n + 127) / 128 * 128 + El * 128;
-  const int64_t max_tiles = capacity / 128;
+  // 256-row tiles when the experts see enough rows to fill them (and the shapes divide): gemm256.hip
+  bool big = n / El >= g_moe_tile256_min_rows;
+  if (g_moe_tile_force) big = g_moe_tile_force == 256;
+  if (tile_rows) big = tile_rows == 256;                     // A/B measurements in one process
+  big = big && I % 128 == 0 && H % 256 == 0 && n * std::max(H, I) * 2 < (int64_t(1) << 32) && 2 * I * H * 2 < (int64_t(1) << 32);
+  const int64_t TR = big ? 256 : 128;
+  const int64_t capacity = (n + TR - 1) / TR * TR + El * TR;
+  const int64_t max_tiles = capacity / TR;
   Tensor ids = at::empty({n}, i32), wts = at::empty({n}, x.options().dtype(at::kFloat));
   Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
   Tensor out = at::empty({T, H}, x.options());
-  if (T <= std::min<int64_t>(g_moe_skinny_max_t, 128) && I % 128 == 0) {
+  if (T <= std::min<int64_t>(g_moe_skinny_max_t, 128) && I % 128 == 0 && tile_rows == 0) {
     // Decode-sized batch: an expert sees ≤ 16 rows (at T ≤ 32 and 2-of-8 routing: nearly always; more rows cost an
     // extra pass over that expert's weights from cache), so both projections are pure weight streams — the
     // weight-streaming kernel of skinny_gemm.hip per (expert, 16 weight rows), SwiGLU in between.
@@ -228,7 +255,7 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
     Tensor y16 = at::empty({n, H}, x.options());
     dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
     dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
-                          tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, stream);
+                          tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, 128, stream);
     dli::launch_moe_skinny(false, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
                            meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, gu.data_ptr(), 2 * I, (int)H, (int)(2 * I),
                            (int)tiles, (int)T, stream);
@@ -244,20 +271,23 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   // Down projection: with few row tiles (decode-sized batches) a (row tile × 128 columns) grid cannot fill 256 CUs and
   // every block would stream a 3.7 MB weight panel through a 16 KB-deep pipeline, so K is cut into slices whose fp32
   // partial slabs are summed (in fixed order) by moe_sum.  The slice count depends on T only: static under hipGraph.
-  const int64_t col_blocks2 = H / 128, nk2 = I / 64;
+  const int64_t col_blocks2 = H / TR, nk2 = I / 64;
   int64_t k_splits = 1;
-  if (max_tiles * col_blocks2 < 1024) k_splits = std::min<int64_t>({(1024 + max_tiles * col_blocks2 - 1) / (max_tiles * col_blocks2), 16, nk2});
+  // (512-thread 256² tiles run one per CU: two full rounds of the chip are enough; the 128² tiles run 2–3 per CU)
+  const int64_t want_blocks = big ? g_moe_splitk_min_blocks256 : 1024;
+  if (max_tiles * col_blocks2 < want_blocks)
+    k_splits = std::min<int64_t>({(want_blocks + max_tiles * col_blocks2 - 1) / (max_tiles * col_blocks2), 16, nk2});
   const bool split = k_splits > 1;
   Tensor y = split ? at::empty({k_splits, n, H}, x.options().dtype(at::kFloat)) : at::empty({n, H}, x.options());
   dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
   dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
-                        tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, stream);
-  dli::launch_grouped_gemm(0, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
-                           meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, act.data_ptr(), I, (int)H, (int)I,
-                           (int)max_tiles, 1, 0, stream);
-  dli::launch_grouped_gemm(split ? 2 : 1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(),
-                           tile_expert.data_ptr<int>(), meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H,
-                           (int)I, (int)H, (int)max_tiles, (int)k_splits, n * H, stream);
+                        tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, (int)TR, stream);
+  auto gg = big ? dli::launch_grouped_gemm256 : dli::launch_grouped_gemm;
+  gg(0, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(), meta.data_ptr<int>(),
+     wts.data_ptr<float>(), (int)top_k, act.data_ptr(), I, (int)H, (int)I, (int)max_tiles, 1, 0, stream);
+  gg(split ? 2 : 1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
+     meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H, (int)I, (int)H, (int)max_tiles, (int)k_splits,
+     n * H, stream);
   dli::launch_moe_sum(y.data_ptr(), split, (int)k_splits, n * H, ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k,
                       (int)T, (int)H, out.data_ptr(), stream);
   return out;
@@ -342,7 +372,8 @@ void ar_all_gather(int64_t st, const Tensor& inp, Tensor out) {
 }  // namespace
 
 TORCH_LIBRARY(dli, m) {
-  m.def("fused_moe(Tensor x, Tensor router_logits, Tensor w13, Tensor w2, int top_k, int expert_offset) -> Tensor", &fused_moe);
+  m.def("fused_moe(Tensor x, Tensor router_logits, Tensor w13, Tensor w2, int top_k, int expert_offset, int tile_rows=0) -> Tensor",
+        &fused_moe);
   m.def("ar_alloc(int bytes, bool uncached) -> int", &ar_alloc);
   m.def("ar_free(int ptr) -> ()", &ar_free);
   m.def("ar_ipc_handle(int ptr) -> Tensor", &ar_ipc_handle);
@@ -363,6 +394,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False) -> Tensor", &skinny_linear);
+  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False) -> Tensor", &dense_gemm256);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
         "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale) -> ()", &rope_and_cache);
   m.def("copy_pages(Tensor(a!) cache, Tensor pairs) -> ()", &copy_pages);

@@ -142,11 +142,32 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return torch.nn.functional.linear(x, weight, bias)
 
 
+GEMM256_SWIGLU = not os.environ.get("DLI_NO_GEMM256_SWIGLU")
+
+
+def gemm256_swiglu_ok(m: int, n_out: int, k: int) -> bool:
+    """Shapes for which the 256×256×64 tile kernel with the SwiGLU epilogue (``csrc/kernels/gemm256.hip``) beats the
+    library GEMM + ``silu_and_mul`` (hipGraph-timed A/B on random data, ``profiles/gemm256_r2e.jsonl``: Llama-3-8B
+    gate/up 1.04–1.18× at M = 512…8192; the Llama-3-70B TP = 8 shard 1.0–1.05× from M = 2048, slower below): the
+    tiles must fill most of the chip (≥ 200 workgroups of one per CU) and their last row tile must not be mostly
+    padding."""
+    if not GEMM256_SWIGLU or m < 448 or n_out % 128 or k % 64:
+        return False
+    tiles = (m + 255) // 256
+    return tiles * (n_out // 128) >= 200 and m >= 0.8 * tiles * 256
+
+
 def linear_swiglu(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """``silu(x @ W_gateᵀ) * (x @ W_upᵀ)`` for a fused ``weight = [W_gate; W_up]``: one kernel at decode size
-    (SwiGLU in the epilogue of the weight-streaming GEMM), library GEMM + ``silu_and_mul`` otherwise."""
+    (SwiGLU in the epilogue of the weight-streaming GEMM) and at prefill size (SwiGLU in the epilogue of the 256² tile
+    GEMM: the ``[T, 2·I]`` intermediate never exists), library GEMM + ``silu_and_mul`` in between."""
     if _skinny_ok(x, weight, 32):
         return hip().skinny_linear(x, weight, None, True)
+    if (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous()
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and gemm256_swiglu_ok(x.shape[0], weight.shape[0] // 2, weight.shape[1])
+            and x.shape[0] * x.stride(0) * 2 < 2 ** 32 and weight.numel() * 2 < 2 ** 32):
+        return hip().dense_gemm256(x, weight, True)
     return silu_and_mul(torch.nn.functional.linear(x, weight))
 
 

@@ -312,3 +312,12 @@ def test_decode_sized_gemm_dispatch_rule():
     torch.testing.assert_close(ops.linear(x, w), torch.nn.functional.linear(x, w))   # CPU tensors: library path
     want = torch.nn.functional.silu(x.float() @ w[:32].float().t()) * (x.float() @ w[32:].float().t())
     torch.testing.assert_close(ops.linear_swiglu(x, w).float(), want, rtol=2e-2, atol=2e-2)
+
+
+def test_gemm256_swiglu_dispatch_rule():
+    """Pure function: which (M, I, K) take the fused large-M gate/up kernel (measured crossovers, profiles/gemm256_r2e.jsonl)."""
+    from dli_amd.ops import gemm256_swiglu_ok
+    assert gemm256_swiglu_ok(4096, 14336, 4096) and gemm256_swiglu_ok(512, 14336, 4096)      # Llama-3-8B
+    assert gemm256_swiglu_ok(2048, 3584, 8192) and not gemm256_swiglu_ok(1024, 3584, 8192)   # Llama-3-70B TP=8 shard
+    assert not gemm256_swiglu_ok(300, 14336, 4096)          # second row tile would be mostly padding
+    assert not gemm256_swiglu_ok(64, 14336, 4096) and not gemm256_swiglu_ok(4096, 1000, 4096)

@@ -270,6 +270,56 @@ def test_fused_moe_matches_reference(T, H, I, E, El, off):
         assert got[none_local].abs().max() == 0 if none_local.any() else True
 
 
+@pytest.mark.parametrize("T,H,I,E,El,off", [(1600, 1024, 512, 8, 8, 0), (2100, 512, 256, 8, 2, 4), (900, 512, 256, 2, 2, 0),
+                                             (700, 4096, 1792, 8, 1, 5)])
+def test_fused_moe_256_row_tiles_match_reference(T, H, I, E, El, off):
+    """≥ 384 routed rows per local expert: the 256×256×64 tile kernel (gemm256.hip) runs both grouped GEMMs."""
+    x = _bf(T, H, seed=51)
+    logits = _bf(T, E, seed=52, scale=2.0)
+    w13 = _bf(El, 2 * I, H, seed=53, scale=0.03)
+    w2 = _bf(El, H, I, seed=54, scale=0.03)
+    got = ops.hip().fused_moe(x, logits, w13, w2, 2, off, 256).float()
+    small = ops.hip().fused_moe(x, logits, w13, w2, 2, off, 128).float()
+    want = ref.moe_ref(x.float(), logits.float(), w13.float(), w2.float(), 2, off).float()
+    scale = want.abs().max().clamp_min(1e-6)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() / scale < 3e-2
+    assert (got - small).abs().max() / scale < 1.5e-2          # the two tilings agree to bf16 rounding of the outputs
+    auto = ops.fused_moe(x, logits, w13, w2, 2, off).float()   # the dispatch rule picks the 256-row tiles here
+    assert torch.equal(auto, got)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 256), (1000, 1024, 4096), (4096, 256, 512), (1, 256, 64), (300, 768, 1024),
+                                   (513, 256, 192)])
+def test_dense_gemm256_matches_fp32_reference(M, N, K):
+    x = _bf(M, K, seed=61)
+    w = _bf(N, K, seed=62, scale=0.05)
+    got = ops.hip().dense_gemm256(x, w, False).float()
+    want = x.float() @ w.float().t()
+    assert got.shape == (M, N) and torch.isfinite(got).all()
+    assert (got - want).abs().max() / want.abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("M,I,K", [(256, 256, 256), (1111, 1792, 4096), (17, 128, 64), (2048, 14336, 512)])
+def test_dense_gemm256_swiglu_epilogue(M, I, K):
+    x = _bf(M, K, seed=63)
+    w = _bf(2 * I, K, seed=64, scale=0.05)
+    got = ops.hip().dense_gemm256(x, w, True).float()
+    h = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(h[:, :I]) * h[:, I:]
+    assert got.shape == (M, I) and torch.isfinite(got).all()
+    assert (got - want).abs().max() / want.abs().max() < 1.5e-2
+
+
+def test_dense_gemm256_identity_check_with_asymmetric_weights():
+    """A = I with an asymmetric W: catches a transposed or permuted C write that symmetric data would hide."""
+    K = N = 256
+    x = torch.eye(K, device=DEV, dtype=torch.bfloat16)
+    w = (torch.arange(N * K, device=DEV, dtype=torch.float32).reshape(N, K) % 251 - 125).to(torch.bfloat16)
+    got = ops.hip().dense_gemm256(x, w, False)
+    assert torch.equal(got.float(), w.float().t())
+
+
 @pytest.mark.parametrize("M,N,K,bias", [(1, 4096, 4096, False), (3, 6144, 4096, True), (16, 28672, 4096, False),
                                          (7, 4096, 14336, False), (16, 128256, 4096, False), (5, 48, 384, True),
                                          (2, 1024, 3584, False)])
