@@ -13,7 +13,13 @@ full ``api_server``).  The harness keeps talking to ONE url; the router picks a 
   is overloaded relative to the least-loaded one (``affinity_slack``).  ``X-Session-Id`` pins a
   session the same way;
 * **health** – a background probe marks replicas down after consecutive failures and routes around
-  them; a request that fails before any byte was relayed is retried on another replica.
+  them; a request that fails before any byte was relayed is retried on another replica, and so is a
+  request that a replica sheds with ``503`` (its admission queue is full); when every replica sheds, the
+  client gets the ``503`` + ``Retry-After`` (the harness records it as a failed request through
+  ``raise_for_status``, `/root/reference/traffic_generator/main.py:258,269-270`);
+* **several router processes** (``--workers N``, one port, ``SO_REUSEPORT``) share ONE load table: the
+  outstanding-token and in-flight counters of every replica live in shared memory (``SharedLoad``), so each
+  worker balances against the traffic of all of them, not just its own.
 
 The wire format is relayed untouched (NDJSON or SSE lines are forwarded as they arrive), so
 ``log.json`` semantics are identical with or without the router.
@@ -51,15 +57,72 @@ def prefix_chain(prompt: str) -> list[int]:
     return out
 
 
+class SharedLoad:
+    """Per-replica (outstanding tokens, in-flight requests, served) counters in shared memory, created before the
+    router workers fork.  Updates take the array's lock for a few hundred nanoseconds; reads are lock-free (a torn
+    read of two counters only perturbs one routing decision)."""
+
+    def __init__(self, n_replicas: int):
+        import multiprocessing as mp
+        self.n = n_replicas
+        self.arr = mp.get_context("fork").Array("q", 3 * n_replicas, lock=True)
+
+    def add(self, idx: int, tokens: int, requests: int, served: int = 0):
+        with self.arr.get_lock():
+            self.arr[3 * idx] += tokens
+            self.arr[3 * idx + 1] += requests
+            self.arr[3 * idx + 2] += served
+
+    def get(self, idx: int):
+        a = self.arr
+        return a[3 * idx], a[3 * idx + 1], a[3 * idx + 2]
+
+
 class Replica:
-    def __init__(self, url: str):
+    def __init__(self, url: str, index: int = 0, shared: Optional[SharedLoad] = None):
         self.url = url.rstrip("/")
-        self.outstanding_tokens = 0
-        self.inflight = 0
+        self.index = index
+        self.shared = shared                 # None: this process is the only router
+        self._tokens = 0
+        self._inflight = 0
+        self._served = 0
         self.healthy = True
         self.fails = 0
-        self.served = 0
         self.errors = 0
+
+    # the load figures every routing decision uses: the totals over ALL router workers when they share a table
+    @property
+    def outstanding_tokens(self) -> int:
+        return self.shared.get(self.index)[0] if self.shared is not None else self._tokens
+
+    @outstanding_tokens.setter
+    def outstanding_tokens(self, v: int):                      # unit tests poke the load directly
+        self._tokens = v
+
+    @property
+    def inflight(self) -> int:
+        return self.shared.get(self.index)[1] if self.shared is not None else self._inflight
+
+    @inflight.setter
+    def inflight(self, v: int):
+        self._inflight = v
+
+    @property
+    def served(self) -> int:
+        return self.shared.get(self.index)[2] if self.shared is not None else self._served
+
+    def acquire(self, cost: int):
+        self._tokens += cost
+        self._inflight += 1
+        if self.shared is not None:
+            self.shared.add(self.index, cost, 1)
+
+    def release(self, cost: int, served: bool = False):
+        self._tokens -= cost
+        self._inflight -= 1
+        self._served += int(served)
+        if self.shared is not None:
+            self.shared.add(self.index, -cost, -1, int(served))
 
     def load(self) -> float:
         return self.outstanding_tokens + 64 * self.inflight
@@ -121,8 +184,9 @@ class RoutingPolicy:
 
 class Router:
     def __init__(self, replica_urls: list[str], health_interval: float = 2.0, max_fails: int = 2, retries: int = 2,
-                 chars_per_token: float = 1.0, **policy_kw):
-        self.replicas = [Replica(u) for u in replica_urls]
+                 chars_per_token: float = 1.0, shared: Optional[SharedLoad] = None, **policy_kw):
+        self.replicas = [Replica(u, i, shared) for i, u in enumerate(replica_urls)]
+        self.shed = 0
         self.policy = RoutingPolicy(self.replicas, **policy_kw)
         self.health_interval = health_interval
         self.max_fails = max_fails
@@ -185,27 +249,38 @@ class Router:
         session_id = request.headers.get("X-Session-Id")
         cost = self._cost(body)
         tried: set[int] = set()
-        for _attempt in range(self.retries + 1):
+        overloaded = None
+        for _attempt in range(max(self.retries + 1, 1)):
             idx = self.policy.choose(chain, session_id, frozenset(tried))
             if idx is None:
                 break
             tried.add(idx)
             rep = self.replicas[idx]
-            rep.outstanding_tokens += cost
-            rep.inflight += 1
+            rep.acquire(cost)
             resp: Optional[web.StreamResponse] = None
+            done = False
             try:
                 async with self.session.post(rep.url + request.path, data=raw,
                                              headers={"Content-Type": "application/json"}) as up:
+                    if up.status == 503:                              # the replica shed it: try the next one
+                        overloaded = (await up.read(), up.headers.get("Retry-After", "1"))
+                        continue
                     resp = web.StreamResponse(status=up.status,
                                               headers={"Content-Type": up.headers.get("Content-Type", "application/json"),
                                                        "X-Served-By": str(idx)})
                     await resp.prepare(request)
                     self.policy.record(idx, chain, session_id)
-                    async for chunk in up.content.iter_any():
-                        await resp.write(chunk)
-                    await resp.write_eof()
-                    rep.served += 1
+                    try:
+                        async for chunk in up.content.iter_any():
+                            await resp.write(chunk)
+                        await resp.write_eof()
+                    except (ConnectionResetError, aiohttp.ClientConnectionResetError):
+                        # the CLIENT went away: leaving the `async with` closes the upstream connection, which aborts
+                        # the request on the replica (frees its KV pages) — not a replica failure
+                        if up.content.exception() is None:
+                            return resp
+                        raise
+                    done = True
                     return resp
             except (aiohttp.ClientConnectionError, asyncio.TimeoutError, aiohttp.ClientPayloadError) as e:
                 rep.errors += 1
@@ -217,9 +292,12 @@ class Router:
                         request.transport.close()
                     return resp
             finally:
-                rep.outstanding_tokens -= cost
-                rep.inflight -= 1
-        return web.json_response({"error": "no healthy replica"}, status=503)
+                rep.release(cost, served=done)
+        self.shed += 1
+        if overloaded is not None:                                   # every replica tried is shedding load
+            return web.Response(body=overloaded[0], status=503, content_type="application/json",
+                                headers={"Retry-After": overloaded[1]})
+        return web.json_response({"error": "no healthy replica"}, status=503, headers={"Retry-After": "1"})
 
     # ------------------------------------------------------------------ introspection
     async def health(self, request):
@@ -228,7 +306,8 @@ class Router:
                                  status=200 if up else 503)
 
     def stats_dict(self) -> dict:
-        return {"decisions": self.policy.decisions, "affinity_hits": self.policy.affinity_hits,
+        return {"decisions": self.policy.decisions, "affinity_hits": self.policy.affinity_hits, "shed": self.shed,
+                "pid": os.getpid(), "shared_load_table": self.replicas[0].shared is not None,
                 "replicas": [{"url": r.url, "healthy": r.healthy, "inflight": r.inflight,
                               "outstanding_tokens": r.outstanding_tokens, "served": r.served, "errors": r.errors}
                              for r in self.replicas]}
@@ -343,8 +422,10 @@ def main(argv=None):
         urls = [u for u in a.replicas.split(",") if u]
     if not urls:
         ap.error("give --replicas or --spawn")
+    shared = SharedLoad(len(urls)) if a.workers > 1 else None      # created before the fork: one table for all workers
+
     def serve():
-        router = Router(urls, affinity_slack=a.affinity_slack, stateless_affinity=a.workers > 1)
+        router = Router(urls, affinity_slack=a.affinity_slack, stateless_affinity=a.workers > 1, shared=shared)
         web.run_app(router.app(), host=a.host, port=a.port, access_log=None, backlog=4096, reuse_port=a.workers > 1,
                     print=None if a.workers > 1 else print)
 

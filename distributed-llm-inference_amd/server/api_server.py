@@ -42,7 +42,7 @@ def _now_iso() -> str:
 
 class ApiServer:
     def __init__(self, cfg: EngineConfig, engine_mode: str = "thread", served_name: str | None = None,
-                 default_max_tokens: int = 128, engine=None):
+                 default_max_tokens: int = 128, engine=None, max_pending_requests: int = 0):
         self.cfg = cfg
         self.aengine = AsyncEngine(cfg, mode=engine_mode, engine=engine)
         self.tokenizer = get_tokenizer(cfg.model, cfg.tokenizer_path)
@@ -50,6 +50,12 @@ class ApiServer:
         self.default_max_tokens = default_max_tokens
         self._ids = itertools.count()
         self.started = time.time()
+        # overload shedding at the door: requests admitted over HTTP that have not produced their first token yet
+        # (queued or prefilling).  Past the limit a new request gets 503 + Retry-After instead of joining a queue
+        # it cannot leave in time (0 = unlimited); the engine's own max_queue_delay is the backstop behind it.
+        self.max_pending_requests = max_pending_requests
+        self._pending = 0
+        self.shed = 0
 
     # ------------------------------------------------------------------ helpers
     def _params(self, body: dict) -> SamplingParams:
@@ -79,6 +85,27 @@ class ApiServer:
     def _bad(msg: str, status: int = 400):
         return web.json_response({"error": msg}, status=status)
 
+    def _overloaded(self):
+        if self.max_pending_requests and self._pending >= self.max_pending_requests:
+            self.shed += 1
+            return web.json_response({"error": "server overloaded: admission queue is full, retry later"}, status=503,
+                                     headers={"Retry-After": "1"})
+        return None
+
+    async def _tracked(self, rid, ids, params):
+        """``aengine.generate`` with the pending-first-token count kept around it."""
+        self._pending += 1
+        waiting = True
+        try:
+            async for item in self.aengine.generate(rid, ids, params):
+                if waiting and (item.token is not None or item.finished):
+                    waiting = False
+                    self._pending -= 1
+                yield item
+        finally:
+            if waiting:
+                self._pending -= 1
+
     async def _json(self, request):
         try:
             body = await request.json()
@@ -97,6 +124,9 @@ class ApiServer:
             return self._bad("'prompt' must be a string")
         model = body.get("model") or self.served_name
         stream = body.get("stream", True)
+        busy = self._overloaded()
+        if busy is not None:
+            return busy
         params = self._params(body)
         ids = self.tokenizer.encode(prompt)
         rid = self._rid("gen")
@@ -111,7 +141,7 @@ class ApiServer:
             await resp.prepare(request)                              # ack now: admission, not first token
             dumps = json.dumps
             try:
-                async for item in self.aengine.generate(rid, ids, params):
+                async for item in self._tracked(rid, ids, params):
                     if item.token is not None:
                         if t_first is None:
                             t_first = time.perf_counter_ns()
@@ -131,7 +161,7 @@ class ApiServer:
             return resp
 
         text = []
-        async for item in self.aengine.generate(rid, ids, params):
+        async for item in self._tracked(rid, ids, params):
             if item.token is not None:
                 if t_first is None:
                     t_first = time.perf_counter_ns()
@@ -173,6 +203,9 @@ class ApiServer:
                 prompt = prompt[0]
             if prompt is not None and not isinstance(prompt, str):
                 return self._bad("'prompt' must be a string or a list of token ids")
+        busy = self._overloaded()
+        if busy is not None:
+            return busy
         ids = body["prompt"] if prompt is None else self.tokenizer.encode(prompt)
         model = body.get("model") or self.served_name
         params = self._params(body)
@@ -194,7 +227,7 @@ class ApiServer:
             resp = web.StreamResponse(headers={"Content-Type": "text/event-stream", "Cache-Control": "no-cache"})
             await resp.prepare(request)
             n_out = n_prompt = 0
-            async for item in self.aengine.generate(rid, ids, params):
+            async for item in self._tracked(rid, ids, params):
                 finish = None
                 if item.finished:
                     finish = "length" if item.reason == "length" else (item.reason or "stop")
@@ -212,7 +245,7 @@ class ApiServer:
             return resp
 
         pieces, finish, n_out, n_prompt = [], "stop", 0, len(ids)
-        async for item in self.aengine.generate(rid, ids, params):
+        async for item in self._tracked(rid, ids, params):
             if item.token is not None:
                 pieces.append(dec.step(item.token))
             if item.finished:
@@ -234,6 +267,8 @@ class ApiServer:
         s = await self.aengine.stats()
         s.pop("prometheus", None)
         s["streams"] = self.aengine.num_streams
+        s["pending_first_token"] = self._pending
+        s["shed_503"] = self.shed
         return web.json_response(s)
 
     async def metrics(self, request):
@@ -298,7 +333,8 @@ def engine_config_from_args(a) -> EngineConfig:
         cache=CacheConfig(kv_dtype=a.kv_dtype, num_blocks=a.num_kv_blocks, gpu_memory_utilization=a.gpu_memory_utilization,
                           enable_prefix_caching=not a.no_prefix_caching),
         sched=SchedulerConfig(max_num_seqs=a.max_num_seqs, max_num_batched_tokens=a.max_num_batched_tokens,
-                              max_model_len=a.max_model_len, long_prefill_chunk=a.prefill_chunk, ttft_slo=a.ttft_slo),
+                              max_model_len=a.max_model_len, long_prefill_chunk=a.prefill_chunk, ttft_slo=a.ttft_slo,
+                              tpot_slo=a.tpot_slo, max_queue_delay=a.max_queue_delay),
         parallel=ParallelConfig(tp=a.tp, ep=a.ep, custom_all_reduce=not a.no_custom_all_reduce),
         device=a.device, seed=a.seed, use_hip_graphs=not a.no_hip_graphs, weights_path=a.weights,
         tokenizer_path=a.tokenizer)
@@ -322,6 +358,10 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--prefill-chunk", type=int, default=2048)
     ap.add_argument("--ttft-slo", type=float, default=None,
                     help="seconds; waiting requests already past this time-to-first-token deadline yield to fresher ones")
+    ap.add_argument("--tpot-slo", type=float, default=None,
+                    help="seconds per output token; the prefill share of a step shrinks while decodes would exceed it")
+    ap.add_argument("--max-queue-delay", type=float, default=None,
+                    help="seconds; a request still not admitted after this long is shed (stream ends with an error line)")
     ap.add_argument("--no-hip-graphs", action="store_true")
     ap.add_argument("--no-custom-all-reduce", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -335,10 +375,12 @@ def main(argv=None):
     ap.add_argument("--served-model-name", default=None)
     ap.add_argument("--engine-mode", default="process", choices=["process", "thread"])
     ap.add_argument("--default-max-tokens", type=int, default=128)
+    ap.add_argument("--max-pending-requests", type=int, default=0,
+                    help="answer 503 + Retry-After once this many requests wait for their first token (0: unlimited)")
     a = ap.parse_args(argv)
     cfg = engine_config_from_args(a)
     server = ApiServer(cfg, engine_mode=a.engine_mode, served_name=a.served_model_name,
-                       default_max_tokens=a.default_max_tokens)
+                       default_max_tokens=a.default_max_tokens, max_pending_requests=a.max_pending_requests)
     web.run_app(server.app(), host=a.host, port=a.port, access_log=None, backlog=4096)
 
 

@@ -8,6 +8,7 @@ import asyncio
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pandas as pd
@@ -282,3 +283,48 @@ def test_analyze_tpot_from_sidecar():
     n_out = analyze.n_out_from_sidecar({"0": {"n_lines": 12}})
     s = analyze.summarize(metrics, n_out, slo_ttft=0.5, slo_tpot=0.2)
     assert n_out == {"0": 11} and abs(s["tpot"]["mean"] - 0.1) < 1e-9 and s["slo_attainment"] == 1.0
+
+
+def test_fresh_clone_invocation_writes_default_log_path(tmp_path):
+    """Contract I1 end to end: `cd traffic_generator && python main.py` on a tree WITHOUT a logs/ directory must still
+    leave `../logs/log.json` behind (the reference ships the directory, `/root/reference/logs/log.json`; its default
+    `log_path` is relative to it, `/root/reference/traffic_generator/main.py:312,343`), byte-pattern-identical to the
+    reference's sample."""
+    import shutil
+    import socket
+    import subprocess
+    import time
+    import synth
+    tree = tmp_path / "clone"
+    shutil.copytree(os.path.join(ROOT, "traffic_generator"), tree / "traffic_generator",
+                    ignore=shutil.ignore_patterns("__pycache__"))
+    os.makedirs(tree / "data")
+    shutil.copy(os.path.join(ROOT, "data", "trace1.csv"), tree / "data" / "trace1.csv")
+    synth.make_conversations(str(tree / "data" / "conversations.json"), n=200, seed=3)
+    assert not (tree / "logs").exists()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tgd = str(tree / "traffic_generator")
+    srv = subprocess.Popen([sys.executable, "fake_server.py", "--port", str(port), "--n-tokens", "5"], cwd=tgd)
+    try:
+        for _ in range(100):
+            try:
+                socket.create_connection(("127.0.0.1", port), timeout=0.2).close()
+                break
+            except OSError:
+                time.sleep(0.1)
+        p = subprocess.run([sys.executable, "main.py", "--url", f"http://127.0.0.1:{port}/api/generate"], cwd=tgd,
+                           capture_output=True, text=True, timeout=120)
+    finally:
+        srv.terminate()
+        srv.wait(10)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "[START] ID: 0" in p.stdout and "[END] ID: 5" in p.stdout
+    out = (tree / "logs" / "log.json").read_text()
+    num = r"-?\d+(?:\.\d+)?(?:e-?\d+)?"
+    ref = "/root/reference/logs/log.json"
+    if os.path.exists(ref):
+        assert re.sub(num, "N", out) == re.sub(num, "N", open(ref).read())
+    # the tracked sample (first-party CPU server on the same trace) has the same shape
+    assert re.sub(num, "N", out) == re.sub(num, "N", open(os.path.join(ROOT, "logs", "log.json")).read())

@@ -3,7 +3,13 @@
 import asyncio
 import json
 
+import os
+import sys
+
 import aiohttp
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "traffic_generator"))
+from fake_server import FakeOllama, start  # noqa: E402
 
 from dli_amd.config import CacheConfig, EngineConfig, SchedulerConfig, get_model_config
 from dli_amd.router.router import Replica, Router, RoutingPolicy, prefix_chain, start_router
@@ -114,3 +120,108 @@ def test_stateless_affinity_is_consistent_across_router_workers():
     a.replicas[target].outstanding_tokens = 0
     a.replicas[target].healthy = b.replicas[target].healthy = False
     assert a.choose(chain) == b.choose(chain) != target
+
+
+def test_two_router_workers_share_one_load_table_over_eight_replicas():
+    """`--workers 2` (two processes on one port): the load counters live in shared memory, so EVERY worker sees the
+    in-flight requests of all workers and the eight replicas end up evenly loaded."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    import os
+
+    async def body():
+        fakes = [FakeOllama(token_delay=0.05, n_tokens=12) for _ in range(8)]
+        started = [await start(f) for f in fakes]
+        urls = [u.rsplit("/api/generate", 1)[0] for _r, u in started]
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        proc = subprocess.Popen([sys.executable, "-m", "dli_amd.router.router", "--replicas", ",".join(urls), "--host", "127.0.0.1",
+                                 "--port", str(port), "--workers", "2"], cwd=root,
+                                env=dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", "")))
+        base = f"http://127.0.0.1:{port}"
+        try:
+            async with aiohttp.ClientSession(connector=aiohttp.TCPConnector(limit=0, force_close=True)) as s:
+                for _ in range(100):
+                    try:
+                        async with s.get(base + "/health") as r:
+                            if r.status == 200:
+                                break
+                    except aiohttp.ClientError:
+                        await asyncio.sleep(0.1)
+
+                async def one(i):
+                    async with s.post(base + "/api/generate", json={"model": "m", "prompt": f"p{i}", "max_tokens": 12}) as r:
+                        assert r.status == 200
+                        return len([l async for l in r.content])
+
+                tasks = [asyncio.create_task(one(i)) for i in range(64)]
+                await asyncio.sleep(0.3)                      # all 64 are streaming now (12 tokens × 50 ms each)
+                seen = {}
+                for _ in range(12):                            # new connections land on either worker
+                    async with s.get(base + "/router/stats") as r:
+                        st = await r.json()
+                    seen[st["pid"]] = st
+                    assert st["shared_load_table"] is True
+                    assert sum(rep["inflight"] for rep in st["replicas"]) == 64        # the GLOBAL figure, from any worker
+                    assert max(rep["inflight"] for rep in st["replicas"]) <= 10
+                lines = await asyncio.gather(*tasks)
+                assert all(n == 13 for n in lines)
+                async with s.get(base + "/router/stats") as r:
+                    st = await r.json()
+                assert sum(rep["served"] for rep in st["replicas"]) == 64 and all(rep["inflight"] == 0 for rep in st["replicas"])
+            assert len(seen) == 2, "the stats probes should have reached both workers"
+            per = [len(f.seen) for f in fakes]
+            assert sum(per) == 64 and min(per) >= 6 and max(per) <= 10, per
+        finally:
+            proc.terminate()
+            proc.wait(10)
+            for r, _u in started:
+                await r.cleanup()
+
+    asyncio.run(body())
+
+
+def test_router_retries_a_shedding_replica_and_relays_503_when_all_shed():
+    from aiohttp import web
+
+    async def body():
+        async def shed(request):
+            return web.json_response({"error": "server overloaded"}, status=503, headers={"Retry-After": "2"})
+
+        async def start_shedder():
+            app = web.Application()
+            app.router.add_post("/api/generate", shed)
+            async def ok(_r):
+                return web.json_response({"status": "ok"})
+            app.router.add_get("/health", ok)
+            runner = web.AppRunner(app)
+            await runner.setup()
+            site = web.TCPSite(runner, "127.0.0.1", 0)
+            await site.start()
+            return runner, f"http://127.0.0.1:{site._server.sockets[0].getsockname()[1]}"
+
+        good = FakeOllama(token_delay=0.001, n_tokens=3)
+        rg, ug = await start(good)
+        rs, us = await start_shedder()
+        router = Router([us, ug.rsplit("/api/generate", 1)[0]], health_interval=5.0)
+        rr, base = await start_router(router)
+        async with aiohttp.ClientSession() as s:
+            for i in range(4):                                  # whichever is tried first, the request ends on the good one
+                async with s.post(base + "/api/generate", json={"model": "m", "prompt": "x" * 10, "max_tokens": 3}) as r:
+                    assert r.status == 200 and r.headers["X-Served-By"] == "1"
+                    assert len([l async for l in r.content]) == 4
+        await rr.cleanup()
+        router2 = Router([us], health_interval=5.0)
+        rr2, base2 = await start_router(router2)
+        async with aiohttp.ClientSession() as s:
+            async with s.post(base2 + "/api/generate", json={"model": "m", "prompt": "x", "max_tokens": 3}) as r:
+                assert r.status == 503 and r.headers["Retry-After"] == "2"
+        assert router2.shed == 1
+        for r in (rr2, rg, rs):
+            await r.cleanup()
+
+    asyncio.run(body())

@@ -161,3 +161,52 @@ def test_harness_replay_trace1_against_first_party_server(tmp_path, mode):
     ends = sorted(e["response_end_time"] for e in m.values())
     starts = sorted(e["first_token_arrive_time"] for e in m.values())
     assert starts[-1] < ends[0] + 30.0
+
+
+def test_overload_is_shed_with_503_and_retry_after():
+    """`max_pending_requests`: past that many requests waiting for their first token the server answers 503 +
+    Retry-After at the door (the harness records it as a failed request via raise_for_status,
+    `/root/reference/traffic_generator/main.py:258,269-270`) instead of queueing without bound."""
+    async def body(server, base):
+        server.max_pending_requests = 2
+        async with aiohttp.ClientSession() as s:
+            async def one(i):
+                async with s.post(base + "/api/generate", json={"model": "m", "prompt": "hello " * 40, "max_tokens": 6}) as r:
+                    if r.status != 200:
+                        return r.status, r.headers.get("Retry-After")
+                    return r.status, len([l async for l in r.content])
+            res = await asyncio.gather(*(one(i) for i in range(12)))
+            ok = [r for r in res if r[0] == 200]
+            shed = [r for r in res if r[0] == 503]
+            assert len(ok) >= 2 and len(shed) >= 1 and len(ok) + len(shed) == 12
+            assert all(r[1] == "1" for r in shed) and all(r[1] == 7 for r in ok)
+            async with s.get(base + "/stats") as r:
+                st = await r.json()
+            assert st["shed_503"] == len(shed) and st["pending_first_token"] == 0
+    with_server(body, mode="thread")
+
+
+def test_engine_sheds_requests_that_waited_too_long():
+    """`max_queue_delay`: a request not admitted in time is finished with reason "shed" — its KV reservation is
+    released and its client gets a final record instead of hanging (bounded deferral)."""
+    from dli_amd.config import CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config
+    from dli_amd.engine.engine import LLMEngine
+    import time
+    cfg = EngineConfig(model=get_model_config("tiny-llama"), cache=CacheConfig(num_blocks=64),
+                       sched=SchedulerConfig(max_num_seqs=1, max_num_batched_tokens=64, max_model_len=256, max_queue_delay=0.05),
+                       device="cpu", use_hip_graphs=False)
+    eng = LLMEngine(cfg)
+    p = SamplingParams(temperature=0.0, max_tokens=30, ignore_eos=True)
+    for i in range(4):
+        eng.add_request(f"r{i}", prompt_ids=list(range(3, 40)), params=p)
+    finished = {}
+    t0 = time.time()
+    while eng.has_unfinished() and time.time() - t0 < 60:
+        for o in eng.step():
+            if o.finished:
+                finished[o.req_id] = o.finish_reason
+        time.sleep(0.005)
+    assert finished["r0"] == "length"
+    assert sorted(finished) == ["r0", "r1", "r2", "r3"] and list(finished.values()).count("shed") >= 2
+    assert eng.metrics.requests_shed == list(finished.values()).count("shed")
+    assert eng.bm.num_free == eng.bm.num_blocks and not eng.requests

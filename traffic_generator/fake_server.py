@@ -69,6 +69,10 @@ class FakeOllama:
     def app(self) -> web.Application:
         app = web.Application()
         app.router.add_post("/api/generate", self.generate)
+
+        async def health(_request):
+            return web.json_response({"status": "ok"})
+        app.router.add_get("/health", health)
         return app
 
 
@@ -80,3 +84,20 @@ async def start(fake: FakeOllama, host: str = "127.0.0.1", port: int = 0):
     await site.start()
     real_port = site._server.sockets[0].getsockname()[1]
     return runner, f"http://{host}:{real_port}/api/generate"
+
+
+def main(argv=None):
+    """``python fake_server.py --port 11434``: stand-alone fake for manual runs and the subprocess tests."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=11434)
+    ap.add_argument("--token-delay", type=float, default=0.001)
+    ap.add_argument("--n-tokens", type=int, default=None)
+    ap.add_argument("--serial", action="store_true")
+    a = ap.parse_args(argv)
+    web.run_app(FakeOllama(a.token_delay, a.n_tokens, a.serial).app(), host=a.host, port=a.port, print=None)
+
+
+if __name__ == "__main__":
+    main()

@@ -258,10 +258,14 @@ class MetricCollector:
         self.sidecar = {}
 
     def save(self, path):
+        # the default '../logs/log.json' must work on a fresh clone too (the reference ships its logs/ directory,
+        # `/root/reference/logs/log.json`; a missing one would lose the whole replay at the very last line)
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         with open(path, 'w') as fh:
             json.dump(self.metrics, fh)
 
     def save_sidecar(self, path):
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         with open(path, 'w') as fh:
             json.dump(self.sidecar, fh)
 
