@@ -459,7 +459,23 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
             cohort_idx = np.flatnonzero((stamps >= ramp) & (stamps < ramp + win))
             fin = [r for r in rp.done if lo <= r.arrival < hi]
             ttft, tpot, ok = request_stats(fin, slo)
-            res = {"offered_qps": q * layout.dp, "cohort": int(len(cohort_idx)), "finished": len(fin), "good": int(ok.sum()),
+            # requests of the cohort still generating when the point ends (outputs of up to 1024 tokens outlast the tail):
+            # judged on what they have shown so far — first token in time, running inter-token time within the SLO;
+            # one that has no first token yet counts as failed once its TTFT budget is spent, and is left out otherwise
+            good_open = n_open = 0
+            for r in rp.live.values():
+                if not (lo <= r.arrival < hi):
+                    continue
+                if r.first_token_time is None:
+                    if t_end - r.arrival > slo[0]:
+                        n_open += 1
+                    continue
+                n_open += 1
+                run = (r.last_token_time - r.first_token_time) / max(r.num_output - r.pending - 1, 1)
+                good_open += int(r.first_token_time - r.arrival <= slo[0] and run <= slo[1])
+            shed_cohort = len(cohort_idx) - len(fin) - sum(1 for r in rp.live.values() if lo <= r.arrival < hi)
+            res = {"offered_qps": q * layout.dp, "cohort": len(fin) + n_open + max(shed_cohort, 0), "finished": len(fin),
+                   "good": int(ok.sum()) + good_open, "still_running": n_open, "shed": max(shed_cohort, 0),
                    "ttft": ttft.tolist(), "tpot": tpot.tolist(), "window_s": win}
             out.append(res)
             rp.drain()
@@ -486,6 +502,7 @@ def sweep_line(args, allstats, layout, qps):
             ttft = np.concatenate([np.array(p["ttft"]) for p in ps])
             tpot = np.concatenate([np.array(p["tpot"]) for p in ps])
             tab.append({"offered_qps": ps[0]["offered_qps"], "arrivals": cohort, "good": good,
+                        "still_running_at_end": sum(p.get("still_running", 0) for p in ps), "shed": sum(p.get("shed", 0) for p in ps),
                         "attainment": round(good / max(cohort, 1), 4),
                         "goodput_req_per_s": round(good / ps[0]["window_s"], 3),
                         "ttft_p50_s": pct(ttft, 50), "ttft_p99_s": pct(ttft, 99),

@@ -36,6 +36,7 @@ struct Seq {
   std::vector<int> blocks;
   int hashed_blocks = 0;    // leading blocks whose chain hash has been computed
   uint64_t chain = 0;       // hash of block hashed_blocks-1 (0 at the root)
+  bool no_publish = false;  // chain lost (copy-on-write below the hashed prefix): commit() leaves this sequence alone
 };
 
 class BlockManager {
@@ -98,6 +99,7 @@ class BlockManager {
   void commit(int64_t id, const int32_t* tok, int n, int num_computed) {
     if (!caching_) return;
     Seq& s = at(id);
+    if (s.no_publish) return;
     if (num_computed > n) num_computed = n;
     const int full = std::min(num_computed / bs_, static_cast<int>(s.blocks.size()));
     for (int b = s.hashed_blocks; b < full; ++b) {
@@ -129,11 +131,13 @@ class BlockManager {
     seqs_.emplace(child, std::move(c));
   }
 
-  // Before appending into the last block: if it is shared, give this sequence a private copy.
-  // Returns (src, dst) for the device-side block copy, or (-1, -1) when nothing has to be copied.
+  // Before writing token number `num_tokens_in_seq` (0-based position) of this sequence: if the block it falls into
+  // is shared, give the sequence a private one.  Returns (src, dst) for the device-side block copy; src = -1 when
+  // the block is replaced but nothing has to be copied (the position is the first of its block: no kept token
+  // lives there); (-1, -1) when the block is already private or not allocated yet.
   std::pair<int, int> cow_tail(int64_t id, int num_tokens_in_seq) {
     Seq& s = at(id);
-    if (s.blocks.empty() || num_tokens_in_seq % bs_ == 0) return {-1, -1};
+    if (s.blocks.empty()) return {-1, -1};
     const int idx = num_tokens_in_seq / bs_;
     if (idx >= static_cast<int>(s.blocks.size())) return {-1, -1};
     const int src = s.blocks[idx];
@@ -142,8 +146,13 @@ class BlockManager {
     const int dst = pop_free();
     --blocks_[src].ref;
     s.blocks[idx] = dst;
-    if (s.hashed_blocks > idx) s.hashed_blocks = idx;
-    return {src, dst};
+    if (s.hashed_blocks > idx) {                             // the private block is not the cached one any more
+      s.hashed_blocks = idx;
+      s.chain = 0;
+      // chain of block idx-1 is not stored per block: stop publishing for this sequence past the fork point
+      s.no_publish = true;
+    }
+    return {num_tokens_in_seq % bs_ == 0 ? -1 : src, dst};
   }
 
   std::vector<int> block_table(int64_t id) const { return at(id).blocks; }

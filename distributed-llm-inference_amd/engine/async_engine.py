@@ -8,9 +8,10 @@ Two transports, one protocol:
   Python work of the HTTP layer (detokenise, JSON, socket writes for thousands of concurrent
   streams) never competes with the scheduler for the GIL.
 
-Messages to the core:   ("add", req_id, prompt_ids, params_dict, arrival) | ("abort", req_id) |
+Messages to the core:   ("add", req_id, prompt_ids, params_dict, arrival, n) | ("abort", req_id) |
                         ("stats",) | ("shutdown",)
-Messages from the core: ("out", [(req_id, token, finished, reason, n_prompt, n_out, n_cached), …]) —
+Messages from the core: ("out", [(req_id, token, finished, reason, n_prompt, n_out, n_cached, choice), …]) —
+                        ``req_id`` is always the id the client used; ``choice`` numbers the n > 1 samples —
                         one message per engine step — | ("stats", dict) | ("ready", info) | ("dead", err)
 """
 from __future__ import annotations
@@ -75,11 +76,11 @@ def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
             msg = chan.recv()
             kind = msg[0]
             if kind == "add":
-                _, rid, ids, pd, arrival = msg
+                _, rid, ids, pd, arrival, n = msg
                 try:
-                    engine.add_request(rid, prompt_ids=ids, params=SamplingParams(**pd), arrival=arrival)
+                    engine.add_request(rid, prompt_ids=ids, params=SamplingParams(**pd), arrival=arrival, n=n)
                 except Exception as e:                       # bad request: report as finished-with-error
-                    chan.send(("out", [(rid, None, True, f"error: {e}", 0, 0, 0)]))
+                    chan.send(("out", [(rid, None, True, f"error: {e}", 0, 0, 0, c) for c in range(max(n, 1))]))
             elif kind == "abort":
                 engine.abort_request(msg[1])
             elif kind == "stats":
@@ -95,8 +96,9 @@ def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
                 chan.send(("dead", traceback.format_exc()))
                 raise
             if outs:
-                chan.send(("out", [(o.req_id, o.new_token_ids[0] if o.new_token_ids else None, o.finished, o.finish_reason, o.num_prompt_tokens,
-                                    o.num_output_tokens, o.num_cached_tokens) for o in outs]))
+                chan.send(("out", [(o.parent_id or o.req_id, o.new_token_ids[0] if o.new_token_ids else None, o.finished,
+                                    o.finish_reason, o.num_prompt_tokens, o.num_output_tokens, o.num_cached_tokens,
+                                    o.sample_index) for o in outs]))
     engine.shutdown()
 
 
@@ -131,6 +133,7 @@ class StreamItem:
     n_prompt: int
     n_out: int
     n_cached: int
+    choice: int = 0
 
 
 class AsyncEngine:
@@ -194,15 +197,15 @@ class AsyncEngine:
     def _on_dead(self, why: str):
         self._dead = why
         for q in self._streams.values():
-            q.put_nowait(StreamItem(None, True, f"error: {why}", 0, 0, 0))
+            q.put_nowait(StreamItem(None, True, f"error: engine {why}", 0, 0, 0))
 
     def _dispatch(self, msg):
         kind = msg[0]
         if kind == "out":
-            for rid, tok, fin, reason, n_p, n_o, n_c in msg[1]:
+            for rid, tok, fin, reason, n_p, n_o, n_c, choice in msg[1]:
                 q = self._streams.get(rid)
                 if q is not None:
-                    q.put_nowait(StreamItem(tok, fin, reason, n_p, n_o, n_c))
+                    q.put_nowait(StreamItem(tok, fin, reason, n_p, n_o, n_c, choice))
         elif kind == "stats":
             for f in self._stats_waiters:
                 if not f.done():
@@ -212,18 +215,22 @@ class AsyncEngine:
             self._on_dead(msg[1])
 
     # ------------------------------------------------------------------ public API
-    async def generate(self, req_id: str, prompt_ids, params: SamplingParams) -> AsyncIterator[StreamItem]:
-        """Yields one ``StreamItem`` per generated token; aborts the request if the consumer goes away."""
+    async def generate(self, req_id: str, prompt_ids, params: SamplingParams, n: int = 1) -> AsyncIterator[StreamItem]:
+        """Yields one ``StreamItem`` per generated token (``item.choice`` tells the n > 1 samples apart; the iterator
+        ends when all ``n`` have finished); aborts the request if the consumer goes away."""
         if self._dead:
             raise RuntimeError(self._dead)
         q: asyncio.Queue = asyncio.Queue()
         self._streams[req_id] = q
-        self._chan.send(("add", req_id, list(map(int, prompt_ids)), dataclasses.asdict(params), time.perf_counter()))
+        self._chan.send(("add", req_id, list(map(int, prompt_ids)), dataclasses.asdict(params), time.perf_counter(), int(n)))
         finished = False
+        open_choices = max(int(n), 1)
         try:
             while True:
                 item = await q.get()
-                finished = item.finished
+                if item.finished:
+                    open_choices -= 1
+                finished = open_choices <= 0 or (item.reason or "").startswith("error: engine")
                 yield item
                 if finished:
                     return

@@ -43,6 +43,7 @@ class LLMEngine:
         if self.ctx.is_driver:
             self.bm = BlockManager(self.runner.num_blocks, KV_BLOCK_SIZE, cfg.cache.enable_prefix_caching)
             self.scheduler = Scheduler(cfg.sched, self.bm)
+            self.scheduler.seq_ids = self._seq_ids
         else:
             self.bm = None
             self.scheduler = None
@@ -62,7 +63,9 @@ class LLMEngine:
 
     # ------------------------------------------------------------------ intake
     def add_request(self, req_id: str, prompt=None, params: Optional[SamplingParams] = None, prompt_ids=None,
-                    arrival: Optional[float] = None, client_tag=None) -> Request:
+                    arrival: Optional[float] = None, client_tag=None, n: int = 1) -> Request:
+        """``n > 1`` (OpenAI ``n``): the prompt is prefilled ONCE; the other ``n - 1`` samples are forked off its KV pages
+        when it completes and appear as requests ``f"{req_id}#{i}"`` (outputs carry ``parent_id`` / ``sample_index``)."""
         if req_id in self.requests:
             raise ValueError(f"duplicate request id {req_id!r}")
         if prompt_ids is None:
@@ -74,6 +77,7 @@ class LLMEngine:
         prompt_ids = np.asarray(prompt_ids, dtype=np.int64) % vocab
         params = (params or SamplingParams()).clamp(max_len, len(prompt_ids))
         req = Request(req_id, next(self._seq_ids), prompt_ids, params, arrival, client_tag)
+        req.n_samples = max(1, int(n))
         if params.seed is None:
             req.seed = (zlib.crc32(req_id.encode()) ^ (self.cfg.seed * 0x9E3779B1)) & 0x7FFFFFFF
         self.requests[req_id] = req
@@ -82,9 +86,12 @@ class LLMEngine:
         return req
 
     def abort_request(self, req_id: str) -> bool:
+        for rid in [r for r, q in self.requests.items() if q.parent_id == req_id]:      # n > 1: the children go with it
+            self.abort_request(rid)
         req = self.requests.pop(req_id, None)
         if req is None:
             return False
+        req.forked = True                                        # an aborted parent must not fork any more
         self.scheduler.abort(req_id, req)
         self.metrics.on_finish(req, aborted=True)
         return True
@@ -134,8 +141,12 @@ class LLMEngine:
                 # (a timed-out custom all-reduce is seen behind EVERY step without a sync and switches the group to
                 #  the library collectives with the next step header: ModelRunner._note_ar_error / _broadcast_step)
             with trace_range(f"launch[T={batch.total_tokens},B={len(batch.requests)}]"):
-                handle = self.runner.launch(batch, self.bm)
+                handle = self.runner.launch(batch, self.bm, self.scheduler.take_copies())
                 self.scheduler.advance(batch, self.cfg.sched.max_model_len)
+                for child in self.scheduler.forked:          # n > 1: children forked off a prompt that just completed
+                    self.requests[child.req_id] = child
+                    self.metrics.requests_total += 1
+                self.scheduler.forked.clear()
             launched = (batch, handle, t1 - t0, t1)
         if self.async_scheduling:
             prev, self._inflight = self._inflight, launched
@@ -154,7 +165,7 @@ class LLMEngine:
             self.metrics.on_finish(req, aborted=True)
             self.metrics.requests_shed += 1
             outs.append(RequestOutput(req.req_id, [], True, RequestStatus.FINISHED_SHED.value, req.num_prompt, 0, 0,
-                                      req.client_tag))
+                                      req.client_tag, req.parent_id, req.sample_index))
         self.scheduler.shed.clear()
         return outs
 
@@ -179,7 +190,8 @@ class LLMEngine:
                 self.requests.pop(req.req_id, None)
                 self.metrics.on_finish(req)
             outs.append(RequestOutput(req.req_id, [tok], fin, status.value if fin else None, req.num_prompt,
-                                      req.num_output, req.num_cached_prompt, req.client_tag))
+                                      req.num_output, req.num_cached_prompt, req.client_tag, req.parent_id,
+                                      req.sample_index))
         # exec = launch → ids on the host (GPU time of the step as the caller sees it)
         self.metrics.on_step(batch, sched_s, t2 - t_launch, time.perf_counter() - t2, self)
         # step-time feedback for the TPOT controller: with a step queued behind this one the GPU never idles, so the

@@ -32,7 +32,7 @@ class Request:
     __slots__ = ("req_id", "seq_id", "params", "tokens", "num_prompt", "num_tokens", "num_computed", "status",
                  "arrival", "first_scheduled", "first_token_time", "finish_time", "num_cached_prompt",
                  "preemptions", "seed", "client_tag", "last_token_time", "token_times", "pending", "sample_row",
-                 "finishing")
+                 "finishing", "n_samples", "parent_id", "sample_index", "forked")
 
     def __init__(self, req_id: str, seq_id: int, prompt_ids, params: SamplingParams, arrival: Optional[float] = None,
                  client_tag=None):
@@ -62,6 +62,12 @@ class Request:
         self.pending = 0
         self.sample_row = -1            # row of this request in the in-flight step's sampler output
         self.finishing = False          # length limit reached at launch time; finishes when resolved
+        # n > 1 sampling (OpenAI `n`): the parent prefills the prompt once; when it completes, n-1 children are forked
+        # off its KV pages (shared, copy-on-write tail) and sample their own continuations
+        self.n_samples = 1
+        self.parent_id = None           # request id of the parent (children only)
+        self.sample_index = 0           # choice index: 0 = the parent itself
+        self.forked = False
 
     @property
     def num_output(self) -> int:
@@ -107,3 +113,5 @@ class RequestOutput:
     num_output_tokens: int = 0
     num_cached_tokens: int = 0
     client_tag: object = None
+    parent_id: Optional[str] = None        # n > 1: the request the client knows; sample_index = its choice number
+    sample_index: int = 0

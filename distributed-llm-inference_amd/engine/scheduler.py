@@ -46,6 +46,9 @@ class Scheduler:
         self.running: list[Request] = []
         self.watermark_blocks = max(int(block_manager.num_blocks * watermark), 1)
         self.num_preemptions = 0
+        self.forked: list[Request] = []                    # children created by n > 1 forks; the engine registers them
+        self.pending_copies: list[tuple[int, int]] = []    # (src page, dst page) copy-on-write work for the next launch
+        self.seq_ids = None                                # iterator of fresh sequence ids (set by the engine)
         self.shed: list[Request] = []                      # finished with status "shed"; the engine reports them
         self.num_shed = 0
         # TPOT controller state
@@ -243,6 +246,38 @@ class Scheduler:
     #   resolve(batch…) – when the sampled ids arrive: fill the placeholders, detect EOS/stop tokens, finish.
     # An EOS found by resolve(N) may come after step N+1 was queued with the same request in it; that
     # step's extra token is dropped (the request is already finished when it resolves).
+    def _fork_children(self, req: Request) -> None:
+        """n > 1: the parent's prompt is in the cache now.  Each child shares the parent's pages (ref-counted), gets a
+        private copy of the page holding the LAST prompt token (copy-on-write, done on the device before the next
+        launch) and recomputes just that token — which yields its own first sample from its own RNG stream without any
+        logits plumbing.  Without room for the private pages the children queue as ordinary requests instead (they
+        still skip the shared prefix through the prefix cache)."""
+        import dataclasses
+        req.forked = True
+        k = req.n_samples - 1
+        room = self.bm.num_free - self.watermark_blocks >= k
+        for i in range(1, req.n_samples):
+            child = Request(f"{req.req_id}#{i}", next(self.seq_ids), req.tokens[:req.num_prompt],
+                            dataclasses.replace(req.params), req.arrival, req.client_tag)
+            child.seed = (req.seed + 0x9E3779B1 * i) & 0x7FFFFFFF
+            child.parent_id, child.sample_index = req.req_id, i
+            child.first_scheduled = req.first_scheduled
+            if room:
+                self.bm.fork(req.seq_id, child.seq_id)
+                src, dst = self.bm.cow_tail(child.seq_id, req.num_prompt - 1)
+                if src >= 0:
+                    self.pending_copies.append((src, dst))
+                child.num_computed = child.num_cached_prompt = req.num_prompt - 1
+                child.status = RequestStatus.RUNNING
+                self.running.append(child)
+            else:
+                self.waiting.append(child)
+            self.forked.append(child)
+
+    def take_copies(self) -> list:
+        out, self.pending_copies = self.pending_copies, []
+        return out
+
     def advance(self, batch: ScheduledBatch, max_model_len: int) -> None:
         j = 0
         for req, n_new, samples in zip(batch.requests, batch.num_new, batch.sample_mask):
@@ -250,6 +285,8 @@ class Scheduler:
             if samples:
                 if req.num_computed - n_new < req.num_prompt:   # this step completes the prompt: publish its pages
                     self.bm.commit(req.seq_id, req.tokens[:req.num_prompt], req.num_prompt)
+                    if req.n_samples > 1 and not req.forked:
+                        self._fork_children(req)
                 req.sample_row = j
                 j += 1
                 req.append(-1)

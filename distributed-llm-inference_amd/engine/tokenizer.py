@@ -76,19 +76,39 @@ class HFTokenizer:
 
 
 class _HFStreamDecoder:
+    """Incremental detokeniser: O(1) amortised work per token.  Only a short window of ids is ever re-decoded —
+    ``ids[prefix:]``, where ``prefix`` trails the emitted text by a few tokens so that the tokenizer sees the context
+    it needs for spacing / byte-fallback merges — instead of the whole sequence per token (O(n²) per stream on the
+    API event loop).  Text is emitted as the difference between the window decoded with and without the new ids; a
+    window ending in an incomplete UTF-8 sequence (U+FFFD) is held back until the next token completes it."""
+
+    KEEP = 6                           # ids of already-emitted context kept in the window
+
     def __init__(self, tok: HFTokenizer):
-        self.tok, self.ids, self.emitted = tok, [], ""
+        self.tok = tok
+        self.ids: list[int] = []
+        self.prefix = 0                # window start
+        self.read = 0                  # ids[prefix:read] have been emitted
 
     def step(self, token_id: int) -> str:
-        self.ids.append(token_id)
-        text = self.tok.decode(self.ids)
-        if text.endswith("�"):
-            return ""
-        new, self.emitted = text[len(self.emitted):], text
-        return new
+        self.ids.append(int(token_id))
+        ids = self.ids
+        old = self.tok.decode(ids[self.prefix:self.read])
+        new = self.tok.decode(ids[self.prefix:])
+        if new.endswith("\ufffd") or len(new) < len(old):
+            return ""                  # incomplete byte sequence: wait for the rest
+        piece = new[len(old):]
+        self.read = len(ids)
+        self.prefix = max(self.read - self.KEEP, self.prefix)
+        return piece
 
     def flush(self) -> str:
-        return ""
+        if self.read == len(self.ids):
+            return ""
+        old = self.tok.decode(self.ids[self.prefix:self.read])
+        new = self.tok.decode(self.ids[self.prefix:])
+        self.read = len(self.ids)
+        return new[len(old):] if len(new) >= len(old) else ""
 
 
 def get_tokenizer(model_cfg, path: Optional[str] = None):

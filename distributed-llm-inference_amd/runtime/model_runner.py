@@ -36,6 +36,8 @@ def _pinned(shape, dtype, pin):
 
 
 class ModelRunner:
+    MAX_COW = 256                      # copy-on-write page pairs per step (n > 1 forks)
+
     def __init__(self, cfg: EngineConfig, ctx: Optional[ParallelContext] = None, device: Optional[torch.device] = None):
         self.cfg = cfg
         self.ctx = ctx or SINGLE
@@ -111,7 +113,8 @@ class ModelRunner:
         max_tiles = T // 16 + B + 1
         fields = [("input", T), ("pos", T), ("slot", T), ("seq_lens", B), ("qsl", B + 1), ("last", B),
                   ("top_k", B), ("temp", B), ("top_p", B), ("seeds", 2 * B), ("steps", 2 * B),
-                  ("src", B), ("tile_seq", max_tiles), ("tile_q0", max_tiles), ("bt", B * self.max_blocks_per_seq)]
+                  ("src", B), ("tile_seq", max_tiles), ("tile_q0", max_tiles), ("cow", 2 * self.MAX_COW),
+                  ("bt", B * self.max_blocks_per_seq)]
         self.layout, off = {}, 0
         for name, n in fields:
             off = (off + 3) // 4 * 4                      # 16-byte aligned regions
@@ -152,8 +155,12 @@ class ModelRunner:
         self.n_bt, self.n_seq_lens, self.n_qsl = nv["bt"], nv["seq_lens"], nv["qsl"]
 
     # ------------------------------------------------------------------ batch → device
-    def _stage(self, batch, bm):
+    def _stage(self, batch, bm, cow=()):
         reqs = batch.requests
+        if len(cow) > self.MAX_COW:
+            raise RuntimeError(f"{len(cow)} copy-on-write pages in one step (limit {self.MAX_COW})")
+        if cow:
+            self.nv["cow"][:2 * len(cow)] = np.asarray(cow, dtype=np.int32).reshape(-1)
         B, T = len(reqs), batch.total_tokens
         nv = self.nv
         seq_ids = np.fromiter((r.seq_id for r in reqs), dtype=np.int64, count=B)
@@ -217,12 +224,12 @@ class ModelRunner:
         return logits
 
     @torch.inference_mode()
-    def launch(self, batch, bm):
+    def launch(self, batch, bm, cow=()):
         """Driver-side first half of a step: stage the batch, (broadcast it to the TP workers,) queue the
         forward pass, the sampler and the D2H copy of the sampled ids.  Returns a handle for ``collect``.
         At most one earlier step may still be uncollected (its sampled ids are then read on the device)."""
         self._bind_host(self._host_idx ^ 1)
-        B, T, S, n_tiles, n_src = self._stage(batch, bm)
+        B, T, S, n_tiles, n_src = self._stage(batch, bm, cow)
         nd = batch.num_decode
         bucket = 0
         if nd == B and S == B and self.on_gpu and self.cfg.use_hip_graphs:
@@ -230,7 +237,7 @@ class ModelRunner:
         splits = 1
         if self.on_gpu and nd and not bucket:
             splits = ops.choose_decode_splits(nd, self.local_kv_heads, int(self.n_seq_lens[:nd].max()))
-        header = (B, T, S, nd, n_tiles, bucket, splits, n_src)
+        header = (B, T, S, nd, n_tiles, bucket, splits, n_src, len(cow))
         if self.ctx.tp_size > 1:
             self._broadcast_step(header)
         return self.run_staged(header)
@@ -258,26 +265,26 @@ class ModelRunner:
         """Driver → workers: the step header over the CPU (gloo) group, the packed step buffer over the device
         path (the IPC broadcast kernel when the custom collectives are up, else the device group's broadcast).
 
-        The header travels as a SUM all-reduce of 9 int64: the driver contributes the 8 header fields, every rank
+        The header travels as a SUM all-reduce of 10 int64: the driver contributes the 9 header fields, every rank
         contributes its "my all-reduce kernel timed out" vote in the last slot — so a time-out seen by ANY rank
         reaches all of them with the next step, and the whole group leaves the custom kernels at the same step."""
         import torch.distributed as dist
         ctx = self.ctx
-        hdr = torch.zeros(9, dtype=torch.int64)
+        hdr = torch.zeros(10, dtype=torch.int64)
         if ctx.is_driver:
-            hdr[:8] = torch.tensor(header, dtype=torch.int64)
-        hdr[8] = self._ar_vote
+            hdr[:9] = torch.tensor(header, dtype=torch.int64)
+        hdr[9] = self._ar_vote
         g = ctx.cpu_group if ctx.cpu_group is not None else ctx.group
         dist.all_reduce(hdr, group=g)
         if int(hdr[0]) < 0:
             return None
-        if int(hdr[8]) > 0 and ctx.custom_ar is not None and ctx.custom_ar.enabled:
+        if int(hdr[9]) > 0 and ctx.custom_ar is not None and ctx.custom_ar.enabled:
             ctx.disable_custom_ar("a rank's kernel gave up waiting for a peer")
             self.graphs.clear()                              # they hold the custom kernels
             self.stats["ar_fallbacks"] += 1
             if dist.get_backend(ctx.group) != "nccl":
                 self.cfg.use_hip_graphs = False              # host-staged collectives cannot be captured
-        head = tuple(int(x) for x in hdr[:8])
+        head = tuple(int(x) for x in hdr[:9])
         if ctx.is_driver:
             self._pad_for(head)
             self._copy_in()
@@ -301,7 +308,7 @@ class ModelRunner:
         if self.ctx.tp_size > 1 and self.ctx.is_driver:
             import torch.distributed as dist
             g = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
-            hdr = torch.zeros(9, dtype=torch.int64)
+            hdr = torch.zeros(10, dtype=torch.int64)
             hdr[0] = -1
             dist.all_reduce(hdr, group=g)
 
@@ -312,12 +319,19 @@ class ModelRunner:
 
     @torch.inference_mode()
     def run_staged(self, header, staged_on_device: bool = False):
-        B, T, S, nd, n_tiles, bucket, splits, n_src = header
+        B, T, S, nd, n_tiles, bucket, splits, n_src, n_cow = header
         tp_staged = self.ctx.tp_size > 1                    # _broadcast_step already padded + copied
         if bucket and not tp_staged:
             self._pad_decode(B, bucket)
         if not tp_staged:
             self._copy_in()
+        if n_cow:
+            # n > 1 forks: give the children private copies of the page they are about to write (every layer's K and V;
+            # stream-ordered behind the step that filled the source pages, ahead of this step's kernels)
+            pairs = self.dv["cow"][:2 * n_cow].view(n_cow, 2)
+            for k_cache, v_cache in self.kv_caches:
+                ops.copy_pages(k_cache, pairs)
+                ops.copy_pages(v_cache, pairs)
         if n_src:
             # decode rows whose input id was sampled by the step still in flight: take it from the sampler's
             # device output (stream order puts this behind that step and ahead of this step's sampler)

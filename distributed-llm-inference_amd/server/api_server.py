@@ -92,12 +92,12 @@ class ApiServer:
                                      headers={"Retry-After": "1"})
         return None
 
-    async def _tracked(self, rid, ids, params):
+    async def _tracked(self, rid, ids, params, n: int = 1):
         """``aengine.generate`` with the pending-first-token count kept around it."""
         self._pending += 1
         waiting = True
         try:
-            async for item in self.aengine.generate(rid, ids, params):
+            async for item in self.aengine.generate(rid, ids, params, n):
                 if waiting and (item.token is not None or item.finished):
                     waiting = False
                     self._pending -= 1
@@ -209,17 +209,24 @@ class ApiServer:
         ids = body["prompt"] if prompt is None else self.tokenizer.encode(prompt)
         model = body.get("model") or self.served_name
         params = self._params(body)
+        # OpenAI `n`: n samples of ONE prompt — prefilled once, the other n-1 forked off its KV pages (copy-on-write)
+        try:
+            n = int(body.get("n") or 1)
+        except (TypeError, ValueError):
+            return self._bad("'n' must be an integer")
+        if not 1 <= n <= 16:
+            return self._bad("'n' must be between 1 and 16")
         rid = self._rid("chatcmpl" if chat else "cmpl")
         created = int(time.time())
         obj = "chat.completion" if chat else "text_completion"
-        dec = self.tokenizer.stream_decoder()
+        decs = [self.tokenizer.stream_decoder() for _ in range(n)]
 
-        def chunk(piece, finish=None, streaming=True):
+        def chunk(piece, finish=None, streaming=True, index=0):
             if chat:
                 key = "delta" if streaming else "message"
-                ch = {"index": 0, key: {"role": "assistant", "content": piece}, "finish_reason": finish}
+                ch = {"index": index, key: {"role": "assistant", "content": piece}, "finish_reason": finish}
             else:
-                ch = {"index": 0, "text": piece, "logprobs": None, "finish_reason": finish}
+                ch = {"index": index, "text": piece, "logprobs": None, "finish_reason": finish}
             return {"id": rid, "object": obj + (".chunk" if chat and streaming else ""), "created": created,
                     "model": model, "choices": [ch]}
 
@@ -227,15 +234,16 @@ class ApiServer:
             resp = web.StreamResponse(headers={"Content-Type": "text/event-stream", "Cache-Control": "no-cache"})
             await resp.prepare(request)
             n_out = n_prompt = 0
-            async for item in self._tracked(rid, ids, params):
+            async for item in self._tracked(rid, ids, params, n):
                 finish = None
+                dec = decs[item.choice]
                 if item.finished:
                     finish = "length" if item.reason == "length" else (item.reason or "stop")
-                    n_out, n_prompt = item.n_out, item.n_prompt
+                    n_out, n_prompt = n_out + item.n_out, item.n_prompt
                 piece = dec.step(item.token) if item.token is not None else ""
                 if item.finished:
                     piece += dec.flush()
-                await resp.write(("data: " + json.dumps(chunk(piece, finish)) + "\n\n").encode())
+                await resp.write(("data: " + json.dumps(chunk(piece, finish, index=item.choice)) + "\n\n").encode())
             if (body.get("stream_options") or {}).get("include_usage"):
                 usage = {"id": rid, "object": obj, "created": created, "model": model, "choices": [],
                          "usage": {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}}
@@ -244,14 +252,16 @@ class ApiServer:
             await resp.write_eof()
             return resp
 
-        pieces, finish, n_out, n_prompt = [], "stop", 0, len(ids)
-        async for item in self._tracked(rid, ids, params):
+        pieces, finish, n_out, n_prompt = [[] for _ in range(n)], ["stop"] * n, 0, len(ids)
+        async for item in self._tracked(rid, ids, params, n):
             if item.token is not None:
-                pieces.append(dec.step(item.token))
+                pieces[item.choice].append(decs[item.choice].step(item.token))
             if item.finished:
-                finish = "length" if item.reason == "length" else (item.reason or "stop")
-                n_out, n_prompt = item.n_out, item.n_prompt
-        out = chunk("".join(pieces) + dec.flush(), finish, streaming=False)
+                finish[item.choice] = "length" if item.reason == "length" else (item.reason or "stop")
+                n_out, n_prompt = n_out + item.n_out, item.n_prompt or n_prompt
+        out = chunk("".join(pieces[0]) + decs[0].flush(), finish[0], streaming=False)
+        for i in range(1, n):
+            out["choices"].append(chunk("".join(pieces[i]) + decs[i].flush(), finish[i], streaming=False, index=i)["choices"][0])
         out["usage"] = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
         return web.json_response(out)
 

@@ -2,7 +2,6 @@
 
 * ``trace_range(name)`` – roctx range (``torch.cuda.nvtx`` is roctx on ROCm) around engine phases, visible in
   ``rocprofv3 --marker-trace`` timelines.  Enabled with ``DLI_PROFILE=1``; a no-op otherwise (zero cost in the hot loop).
-* ``StepTimer`` – host-side wall-clock breakdown of engine steps, exported through ``/stats``.
 * The counter recipes used for ``profiles/`` live in ``docs/PROFILING.md``.
 """
 from __future__ import annotations
@@ -36,17 +35,3 @@ _NULL = contextlib.nullcontext()
 
 def trace_range(name: str):
     return _range(name) if _nvtx is not None else _NULL
-
-
-class StepTimer:
-    def __init__(self):
-        self.totals: dict[str, float] = {}
-        self._t = None
-
-    def start(self):
-        self._t = time.perf_counter()
-
-    def lap(self, name: str):
-        now = time.perf_counter()
-        self.totals[name] = self.totals.get(name, 0.0) + now - self._t
-        self._t = now

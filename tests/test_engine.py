@@ -321,3 +321,87 @@ def test_gemm256_swiglu_dispatch_rule():
     assert gemm256_swiglu_ok(2048, 3584, 8192) and not gemm256_swiglu_ok(1024, 3584, 8192)   # Llama-3-70B TP=8 shard
     assert not gemm256_swiglu_ok(300, 14336, 4096)          # second row tile would be mostly padding
     assert not gemm256_swiglu_ok(64, 14336, 4096) and not gemm256_swiglu_ok(4096, 1000, 4096)
+
+
+@pytest.mark.parametrize("plen", [70, 64, 65, 5])
+def test_n_samples_fork_off_one_prefill(plen):
+    """OpenAI `n`: the prompt is prefilled once; the other samples are forked off its KV pages (ref-counted, private
+    copy of the page with the last prompt token) and recompute only that token.  Greedy children must reproduce the
+    parent exactly — which they only do if the copied / shared pages hold the right K/V — for prompt lengths that end
+    inside a page, on a page boundary, and one past it."""
+    from dli_amd.config import CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config
+    from dli_amd.engine.engine import LLMEngine
+    cfg = EngineConfig(model=get_model_config("tiny-llama"), cache=CacheConfig(num_blocks=64),
+                       sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=128, max_model_len=256),
+                       device="cpu", use_hip_graphs=False)
+    rng = np.random.default_rng(plen)
+    prompt = rng.integers(3, 500, size=plen).tolist()
+    greedy = SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True)
+    want = LLMEngine(cfg).generate(None, greedy, prompt_ids=[prompt])[0]
+
+    eng = LLMEngine(cfg)
+    eng.add_request("r", prompt_ids=prompt, params=greedy, n=3)
+    outs = {}
+    while eng.has_unfinished():
+        for o in eng.step():
+            outs.setdefault((o.parent_id or o.req_id, o.sample_index), []).extend(o.new_token_ids)
+    assert sorted(outs) == [("r", 0), ("r", 1), ("r", 2)]
+    assert all(v == want for v in outs.values()), (outs, want)
+    # one prefill + one recomputed token per child + the decode steps: far less than three prefills
+    assert eng.metrics.step_tokens == plen + 2 + 3 * 11
+    assert eng.bm.num_free == eng.bm.num_blocks and not eng.requests
+
+    # sampled: every choice draws from its own RNG stream
+    eng2 = LLMEngine(cfg)
+    eng2.add_request("s", prompt_ids=prompt, params=SamplingParams(temperature=1.0, max_tokens=12, ignore_eos=True, seed=3), n=4)
+    outs2 = {}
+    while eng2.has_unfinished():
+        for o in eng2.step():
+            outs2.setdefault(o.sample_index, []).extend(o.new_token_ids)
+    assert len(outs2) == 4 and len({tuple(v) for v in outs2.values()}) >= 3
+
+
+def test_n_samples_without_room_for_private_pages_queue_as_plain_requests():
+    from dli_amd.config import CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config
+    from dli_amd.engine.engine import LLMEngine
+    cfg = EngineConfig(model=get_model_config("tiny-llama"), cache=CacheConfig(num_blocks=6),
+                       sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=128, max_model_len=128),
+                       device="cpu", use_hip_graphs=False)
+    eng = LLMEngine(cfg)
+    assert eng.scheduler.watermark_blocks == 1               # 6 pages, 3 taken by the prompt, 1 reserved: no room for 3 forks
+    p = SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True)
+    eng.add_request("r", prompt_ids=list(range(3, 93)), params=p, n=4)
+    done = {}
+    for _ in range(400):
+        if not eng.has_unfinished():
+            break
+        for o in eng.step():
+            if o.finished:
+                done[o.sample_index] = o.finish_reason
+    assert done == {0: "length", 1: "length", 2: "length", 3: "length"}
+    assert eng.bm.num_free == eng.bm.num_blocks
+
+
+def test_hf_stream_decoder_is_incremental_and_exact(tmp_path):
+    """The streaming detokeniser re-decodes a short window per token (not the whole id list) and still reproduces the
+    text exactly, multi-byte characters split over several byte-level tokens included."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers, trainers
+    from dli_amd.engine.tokenizer import HFTokenizer
+    tk = Tokenizer(models.BPE(unk_token=None))
+    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tk.decoder = decoders.ByteLevel()
+    corpus = ["the quick brown fox jumps over the lazy dog " * 3, "distributed inference engines batch tokens"] * 10
+    tk.train_from_iterator(corpus, trainers.BpeTrainer(vocab_size=300, initial_alphabet=pre_tokenizers.ByteLevel.alphabet()))
+    path = str(tmp_path / "tokenizer.json")
+    tk.save(path)
+    tok = HFTokenizer(path, 1, 2)
+    calls = []
+    real = tok.decode
+    tok.decode = lambda ids: (calls.append(len(ids)), real(ids))[1]
+    text = "héllo wörld ✓ 漢字 🙂 the quick brown fox — " * 12
+    ids = tok.encode(text, add_bos=False)
+    assert len(ids) > 200
+    dec = tok.stream_decoder()
+    out = "".join(dec.step(i) for i in ids) + dec.flush()
+    assert out == text
+    assert max(calls) <= 32, "a decode call must never see more than a short window of ids"

@@ -210,3 +210,28 @@ def test_engine_sheds_requests_that_waited_too_long():
     assert sorted(finished) == ["r0", "r1", "r2", "r3"] and list(finished.values()).count("shed") >= 2
     assert eng.metrics.requests_shed == list(finished.values()).count("shed")
     assert eng.bm.num_free == eng.bm.num_blocks and not eng.requests
+
+
+def test_openai_n_choices_share_one_prefill():
+    """`n` on /v1/completions: n choices (indexed) from one request, streamed and not."""
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            req = {"model": "m", "prompt": "tell me three things " * 5, "max_tokens": 6, "temperature": 0.9, "n": 3, "seed": 4}
+            async with s.post(base + "/v1/completions", json=req) as r:
+                assert r.status == 200
+                out = await r.json()
+            assert [c["index"] for c in out["choices"]] == [0, 1, 2]
+            assert out["usage"]["completion_tokens"] == 18
+            async with s.post(base + "/v1/completions", json=dict(req, stream=True)) as r:
+                chunks = [json.loads(l[6:]) async for l in r.content if l.startswith(b"data: {")]
+            per = {}
+            for c in chunks:
+                ch = c["choices"][0]
+                per.setdefault(ch["index"], []).append(ch["finish_reason"])
+            assert sorted(per) == [0, 1, 2] and all(v[-1] == "length" and len(v) == 6 for v in per.values())
+            async with s.post(base + "/v1/completions", json=dict(req, n=99)) as r:
+                assert r.status == 400
+            async with s.get(base + "/stats") as r:
+                st = await r.json()
+            assert st["num_running"] == 0 and st["pending_first_token"] == 0
+    with_server(body, mode="thread")
