@@ -99,7 +99,8 @@ def get_model_config(name: str, **overrides) -> ModelConfig:
 @dataclass
 class CacheConfig:
     block_size: int = KV_BLOCK_SIZE
-    kv_dtype: str = "auto"              # "auto" (= model dtype) | "fp8" (OCP e4m3, per-tensor scale)
+    kv_dtype: str = "auto"              # "auto" (= model dtype) | "fp8" (OCP e4m3, per-layer per-kv-head scales)
+    calibrate_fp8_scales: bool = True   # fp8: set the scales from a warm-up prefill (amax / 448); False keeps 1.0
     num_blocks: Optional[int] = None    # None → size from free HBM after weights + activation peak
     gpu_memory_utilization: float = 0.92
     enable_prefix_caching: bool = True

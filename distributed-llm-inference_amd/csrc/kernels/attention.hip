@@ -157,9 +157,13 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens, uint16_t* __restrict__ out,
     int64_t out_stride, float* __restrict__ part_o, float* __restrict__ part_ml, int Hq, int Hkv, int num_splits,
-    float scale_log2, float v_scale) {
+    float scale_log2, float v_scale, const float* __restrict__ kv_scales) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int seq = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+  if (KV8 && kv_scales != nullptr) {                       // calibrated per-(layer, kv head) fp8 scales: [k | v][Hkv]
+    scale_log2 *= kv_scales[kvh];
+    v_scale = kv_scales[Hkv + kvh];
+  }
   const int G = Hq / Hkv;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, g = lane >> 4;
@@ -256,8 +260,10 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 // grid (num_seqs, Hq), 128 threads: combine the split partials.
 __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                             uint16_t* __restrict__ out, int64_t out_stride, int Hq,
-                                                            int num_splits, float v_scale) {
+                                                            int num_splits, float v_scale, const float* __restrict__ kv_scales,
+                                                            int Hkv) {
   const int seq = blockIdx.x, qh = blockIdx.y, d = threadIdx.x;
+  if (kv_scales != nullptr) v_scale = kv_scales[Hkv + qh / (Hq / Hkv)];
   const int64_t base = ((int64_t)seq * Hq + qh) * num_splits;
   float M = NEG_BIG;
   for (int s = 0; s < num_splits; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
@@ -293,7 +299,12 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens,
     const int* __restrict__ query_start_loc, const int* __restrict__ tile_seq, const int* __restrict__ tile_q0,
-    uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, float scale_log2, float v_scale) {
+    uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, float scale_log2, float v_scale,
+    const float* __restrict__ kv_scales) {
+  if (KV8 && kv_scales != nullptr) {
+    scale_log2 *= kv_scales[blockIdx.y];
+    v_scale = kv_scales[Hkv + blockIdx.y];
+  }
   constexpr int ESZ = KV8 ? 1 : 2;
   constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;            // one K (or V) page of one kv head
   constexpr int NCH = PAGE_BYTES / (16 * 256);            // 16-byte chunks per thread and operand: 2 (bf16) / 1 (fp8)
@@ -466,40 +477,43 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
 void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                          const int* block_tables, int max_blocks, const int* seq_lens, void* out, int64_t out_stride,
                          float* part_o, float* part_ml, int num_seqs, int Hq, int Hkv, int num_splits, float scale,
-                         bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
+                         bool kv_fp8, float k_scale, float v_scale, const float* kv_scales, hipStream_t stream) {
   if (num_seqs == 0) return;
   const int G = Hq / Hkv;
+  if (kv_scales != nullptr) k_scale = v_scale = 1.f;        // the kernels read the per-head values themselves
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
   const size_t lds = (size_t)(4 * G * HD + 8 * G) * sizeof(float);
   dim3 grid(num_seqs, Hkv, num_splits);
   if (kv_fp8)
     hipLaunchKernelGGL(paged_decode_kernel<true>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
-                       num_splits, scale_log2, v_scale);
+                       num_splits, scale_log2, v_scale, kv_scales);
   else
     hipLaunchKernelGGL(paged_decode_kernel<false>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
-                       num_splits, scale_log2, 1.f);
+                       num_splits, scale_log2, 1.f, nullptr);
   if (num_splits > 1)
     hipLaunchKernelGGL(decode_reduce_kernel, dim3(num_seqs, Hq), dim3(128), 0, stream, part_o, part_ml, (uint16_t*)out,
-                       out_stride, Hq, num_splits, kv_fp8 ? v_scale : 1.f);
+                       out_stride, Hq, num_splits, kv_fp8 ? v_scale : 1.f, kv_fp8 ? kv_scales : nullptr, Hkv);
 }
 
 void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                           const int* block_tables, int max_blocks, const int* seq_lens, const int* query_start_loc,
                           const int* tile_seq, const int* tile_q0, int num_tiles, void* out, int64_t out_stride, int Hq,
-                          int Hkv, float scale, bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
+                          int Hkv, float scale, bool kv_fp8, float k_scale, float v_scale, const float* kv_scales,
+                          hipStream_t stream) {
   if (num_tiles == 0) return;
+  if (kv_scales != nullptr) k_scale = v_scale = 1.f;
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
   dim3 grid(num_tiles, Hkv);
   if (kv_fp8)
     hipLaunchKernelGGL(paged_prefill_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
-                       out_stride, Hq, Hkv, scale_log2, v_scale);
+                       out_stride, Hq, Hkv, scale_log2, v_scale, kv_scales);
   else
     hipLaunchKernelGGL(paged_prefill_kernel<false>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
-                       out_stride, Hq, Hkv, scale_log2, 1.f);
+                       out_stride, Hq, Hkv, scale_log2, 1.f, nullptr);
 }
 
 }  // namespace dli

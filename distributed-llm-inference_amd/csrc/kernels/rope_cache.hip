@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
                                                          const float* __restrict__ cos_sin,  // [max_pos, D] or null
                                                          const int* __restrict__ slot_mapping,
                                                          void* __restrict__ k_cache_, void* __restrict__ v_cache_,
-                                                         int T, int Hq, int Hkv, float k_inv_scale, float v_inv_scale) {
+                                                         int T, int Hq, int Hkv, float k_inv_scale_, float v_inv_scale_,
+                                                         const float* __restrict__ kv_scales) {   // [k | v][Hkv] or null
   const int t0 = blockIdx.x * TB;
   const int nt = min(TB, T - t0);
   const int n_rot = (Hq + Hkv) * 8;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
         *reinterpret_cast<bf16x8*>(kc + ((d1 >> 5) * 32 + tok) * 32 + (d1 & 31)) = b;
       } else {
         uint8_t* kc = reinterpret_cast<uint8_t*>(k_cache_) + page * (D * 32);
+        const float k_inv_scale = kv_scales != nullptr ? fast_rcp(kv_scales[h]) : k_inv_scale_;
         uint64_t pa = 0, pb = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
         }
       } else {
         uint8_t* vc = reinterpret_cast<uint8_t*>(v_cache_) + page * (D * 32) + d0 * 32 + sl;
+        const float v_inv_scale = kv_scales != nullptr ? fast_rcp(kv_scales[Hkv + h]) : v_inv_scale_;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           uint32_t w = 0;
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
         for (int e = 0; e < 8; ++e) vc[e * 32] = (uint16_t)a[e];
       } else {
         uint8_t* vc = reinterpret_cast<uint8_t*>(v_cache_) + page * (D * 32) + d0 * 32 + sl;
+        const float v_inv_scale = kv_scales != nullptr ? fast_rcp(kv_scales[Hkv + h]) : v_inv_scale_;
 #pragma unroll
         for (int e = 0; e < 8; ++e) vc[e * 32] = f_to_fp8(bf2f((uint16_t)a[e]) * v_inv_scale);
       }
@@ -143,11 +147,11 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
 
 void launch_rope_and_cache(void* qkv, int64_t row_stride, const int* positions, const float* cos_sin,
                            const int* slot_mapping, void* k_cache, void* v_cache, int T, int Hq, int Hkv,
-                           bool kv_fp8, float k_scale, float v_scale, hipStream_t stream) {
+                           bool kv_fp8, float k_scale, float v_scale, const float* kv_scales, hipStream_t stream) {
   if (T == 0) return;
 #define DLI_ROPE(KV8_, TB_, ks_, vs_)                                                                                   \
   hipLaunchKernelGGL((rope_cache_kernel<KV8_, TB_>), dim3((T + TB_ - 1) / TB_), dim3(256), 0, stream, (uint16_t*)qkv,   \
-                     row_stride, positions, cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, ks_, vs_)
+                     row_stride, positions, cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, ks_, vs_, kv_fp8 ? kv_scales : nullptr)
   const bool small = T <= 128;                          // ≤ 128 workgroups either way: take the short dependency chain
   if (kv_fp8) {
     if (small) DLI_ROPE(true, 1, 1.f / k_scale, 1.f / v_scale);

@@ -89,8 +89,17 @@ void check_cache(const Tensor& k_cache, const Tensor& v_cache, int64_t Hkv) {
               "K cache must be [blocks, Hkv, 128/CH, 32, CH] with 64-byte chunks");
 }
 
+// per-(layer, kv head) fp8 scales: float32 [2, Hkv] on the GPU (row 0: K, row 1: V), or absent → the scalar arguments
+const float* scales_ptr(const c10::optional<Tensor>& kv_scales, int64_t Hkv) {
+  if (!kv_scales.has_value()) return nullptr;
+  TORCH_CHECK(kv_scales->is_cuda() && kv_scales->scalar_type() == at::kFloat && kv_scales->is_contiguous() &&
+                  kv_scales->numel() == 2 * Hkv, "kv_scales must be a contiguous float32 GPU tensor of 2 × Hkv values");
+  return kv_scales->data_ptr<float>();
+}
+
 void rope_and_cache(Tensor qkv, const Tensor& positions, const c10::optional<Tensor>& cos_sin, const Tensor& slot_mapping,
-                    Tensor k_cache, Tensor v_cache, int64_t Hq, int64_t Hkv, double k_scale, double v_scale) {
+                    Tensor k_cache, Tensor v_cache, int64_t Hq, int64_t Hkv, double k_scale, double v_scale,
+                    const c10::optional<Tensor>& kv_scales) {
   check_bf16_rows(qkv, "qkv");
   check_i32(positions, "positions");
   check_i32(slot_mapping, "slot_mapping");
@@ -105,7 +114,7 @@ void rope_and_cache(Tensor qkv, const Tensor& positions, const c10::optional<Ten
   }
   dli::launch_rope_and_cache(qkv.data_ptr(), qkv.stride(0), positions.data_ptr<int>(), cs, slot_mapping.data_ptr<int>(),
                              k_cache.data_ptr(), v_cache.data_ptr(), (int)T, (int)Hq, (int)Hkv, is_fp8(k_cache), (float)k_scale,
-                             (float)v_scale, cur_stream(qkv));
+                             (float)v_scale, scales_ptr(kv_scales, Hkv), cur_stream(qkv));
 }
 
 void copy_pages(Tensor cache, const Tensor& pairs) {
@@ -119,7 +128,8 @@ void copy_pages(Tensor cache, const Tensor& pairs) {
 // q: [T, Hq*128] view (row stride arbitrary); the first num_seqs rows are the decode queries.
 void paged_attention_decode(Tensor out, const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& block_tables,
                             const Tensor& seq_lens, int64_t num_seqs, int64_t Hq, int64_t Hkv, double scale, int64_t num_splits,
-                            const c10::optional<Tensor>& workspace, double k_scale, double v_scale) {
+                            const c10::optional<Tensor>& workspace, double k_scale, double v_scale,
+                            const c10::optional<Tensor>& kv_scales) {
   check_bf16_rows(q, "q");
   check_bf16_rows(out, "out");
   check_i32(block_tables, "block_tables");
@@ -141,12 +151,13 @@ void paged_attention_decode(Tensor out, const Tensor& q, const Tensor& k_cache, 
   dli::launch_paged_decode(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr<int>(),
                            (int)block_tables.size(1), seq_lens.data_ptr<int>(), out.data_ptr(), out.stride(0), part_o, part_ml,
                            (int)num_seqs, (int)Hq, (int)Hkv, (int)num_splits, (float)scale, is_fp8(k_cache), (float)k_scale,
-                           (float)v_scale, cur_stream(q));
+                           (float)v_scale, scales_ptr(kv_scales, Hkv), cur_stream(q));
 }
 
 void paged_attention_prefill(Tensor out, const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& block_tables,
                              const Tensor& seq_lens, const Tensor& query_start_loc, const Tensor& tile_seq, const Tensor& tile_q0,
-                             int64_t num_tiles, int64_t Hq, int64_t Hkv, double scale, double k_scale, double v_scale) {
+                             int64_t num_tiles, int64_t Hq, int64_t Hkv, double scale, double k_scale, double v_scale,
+                             const c10::optional<Tensor>& kv_scales) {
   check_bf16_rows(q, "q");
   check_bf16_rows(out, "out");
   check_i32(block_tables, "block_tables");
@@ -162,7 +173,8 @@ void paged_attention_prefill(Tensor out, const Tensor& q, const Tensor& k_cache,
   dli::launch_paged_prefill(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr<int>(),
                             (int)block_tables.size(1), seq_lens.data_ptr<int>(), query_start_loc.data_ptr<int>(),
                             tile_seq.data_ptr<int>(), tile_q0.data_ptr<int>(), (int)num_tiles, out.data_ptr(), out.stride(0),
-                            (int)Hq, (int)Hkv, (float)scale, is_fp8(k_cache), (float)k_scale, (float)v_scale, cur_stream(q));
+                            (int)Hq, (int)Hkv, (float)scale, is_fp8(k_cache), (float)k_scale, (float)v_scale,
+                            scales_ptr(kv_scales, Hkv), cur_stream(q));
 }
 
 void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const Tensor& top_p, const Tensor& top_k,
@@ -396,14 +408,15 @@ TORCH_LIBRARY(dli, m) {
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False) -> Tensor", &skinny_linear);
   m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False) -> Tensor", &dense_gemm256);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
-        "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale) -> ()", &rope_and_cache);
+        "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale, Tensor? kv_scales=None) -> ()",
+        &rope_and_cache);
   m.def("copy_pages(Tensor(a!) cache, Tensor pairs) -> ()", &copy_pages);
   m.def("paged_attention_decode(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, Tensor seq_lens, "
         "int num_seqs, int num_heads, int num_kv_heads, float scale, int num_splits, Tensor? workspace, float k_scale, "
-        "float v_scale) -> ()", &paged_attention_decode);
+        "float v_scale, Tensor? kv_scales=None) -> ()", &paged_attention_decode);
   m.def("paged_attention_prefill(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, Tensor seq_lens, "
         "Tensor query_start_loc, Tensor tile_seq, Tensor tile_q0, int num_tiles, int num_heads, int num_kv_heads, float scale, "
-        "float k_scale, float v_scale) -> ()", &paged_attention_prefill);
+        "float k_scale, float v_scale, Tensor? kv_scales=None) -> ()", &paged_attention_prefill);
   m.def("gather_sampled(Tensor(a!) input, Tensor src, Tensor sampled) -> ()", &gather_sampled);
   m.def("sample(Tensor(a!) out, Tensor logits, Tensor temperature, Tensor top_p, Tensor top_k, Tensor seeds, Tensor steps, "
         "Tensor? noise) -> ()", &sample);

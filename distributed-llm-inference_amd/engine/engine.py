@@ -223,6 +223,8 @@ class LLMEngine:
         spin-waiting all-reduce kernel."""
         self._warmed = True
         self.ctx.barrier()
+        if self.cfg.cache.kv_dtype == "fp8" and self.cfg.cache.calibrate_fp8_scales:
+            self.runner.calibrate_kv_scales()
         if capture_graphs:
             self.runner.capture_all()
         self.runner.startup_selftest()

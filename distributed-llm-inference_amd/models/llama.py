@@ -67,14 +67,36 @@ class Attention(nn.Module):
         self.rope = rope
         self.k_scale = 1.0
         self.v_scale = 1.0
+        # fp8 KV cache: per-(layer, kv head) scales [2, Hkv] (K row, V row) on the device, set by the warm-up calibration
+        # (ModelRunner.calibrate_kv_scales); the kernels read them at run time, so decode graphs see updates
+        self.kv_scales = None
+        self.calibrating = False
+        self._calibrated = False
+
+    def enable_kv_scales(self, device):
+        self.kv_scales = torch.ones(2, self.hkv, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def _observe(self, qkv):
+        """Calibration pass: running per-head amax of K (rotation-invariant bound: the norm of each rotated pair) and V
+        of this step's tokens → scale = 1.2 · amax / 448 (e4m3 max), before they are written to the cache."""
+        T, hq, hkv, d = qkv.shape[0], self.hq, self.hkv, self.d
+        k = qkv[:, hq * d:(hq + hkv) * d].float().view(T, hkv, 2, d // 2)
+        v = qkv[:, (hq + hkv) * d:].float().view(T, hkv, d)
+        amax = torch.stack([k.pow(2).sum(2).sqrt().amax((0, 2)), v.abs().amax((0, 2))])
+        new = amax.clamp_min(1e-4) * (1.2 / 448.0)
+        self.kv_scales.copy_(torch.maximum(self.kv_scales, new) if self._calibrated else new)
+        self._calibrated = True
 
     def forward(self, h, meta, kv, cos_sin):
         qkv = self.qkv(h)
         k_cache, v_cache = kv
+        if self.calibrating and self.kv_scales is not None:
+            self._observe(qkv)
         ops.rope_and_cache(qkv, meta.positions, cos_sin if self.rope else None, meta.slot_mapping, k_cache, v_cache,
-                           self.hq, self.hkv, self.d, self.k_scale, self.v_scale)
+                           self.hq, self.hkv, self.d, self.k_scale, self.v_scale, self.kv_scales)
         a = ops.paged_attention(qkv, k_cache, v_cache, meta, self.hq, self.hkv, self.d, self.scale,
-                                self.k_scale, self.v_scale)
+                                self.k_scale, self.v_scale, kv_scales=self.kv_scales)
         return self.o(a)
 
 

@@ -174,20 +174,25 @@ def linear_swiglu(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
 def rope_and_cache(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: Optional[torch.Tensor],
                    slot_mapping: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                    num_heads: int, num_kv_heads: int, head_dim: int,
-                   k_scale: float = 1.0, v_scale: float = 1.0) -> None:
+                   k_scale: float = 1.0, v_scale: float = 1.0, kv_scales: Optional[torch.Tensor] = None) -> None:
+    """``kv_scales``: float32 ``[2, Hkv]`` (row 0 K, row 1 V) per-head scales of an fp8 cache — calibrated values living
+    on the device (hipGraph replays read them at run time); the scalar ``k_scale`` / ``v_scale`` apply without it."""
     if _gpu_kernel_ok(qkv):
         if head_dim != 128:
             raise ValueError("the gfx950 rope/cache kernel is specialised for head_dim 128")
         hip().rope_and_cache(qkv, positions, cos_sin, slot_mapping, k_cache, v_cache, num_heads, num_kv_heads,
-                             k_scale, v_scale)
+                             k_scale, v_scale, kv_scales)
     else:
+        if kv_scales is not None:
+            k_scale, v_scale = kv_scales[0], kv_scales[1]
         ref.rope_and_cache_ref(qkv, positions, cos_sin, slot_mapping, k_cache, v_cache, num_heads, num_kv_heads,
                                head_dim, k_scale, v_scale)
 
 
 def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, meta: AttnMetadata,
                     num_heads: int, num_kv_heads: int, head_dim: int, scale: float,
-                    k_scale: float = 1.0, v_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    k_scale: float = 1.0, v_scale: float = 1.0, out: Optional[torch.Tensor] = None,
+                    kv_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention of this step's tokens over the paged cache (which already holds their K/V).
     ``qkv [T, (Hq+2Hkv)·D]`` — only the q columns are read.  Returns ``[T, Hq·D]``."""
     T = qkv.shape[0]
@@ -201,13 +206,15 @@ def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
         if meta.num_decode > 0:
             lib.paged_attention_decode(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens, meta.num_decode,
                                        num_heads, num_kv_heads, scale, meta.decode_splits, meta.decode_workspace,
-                                       k_scale, v_scale)
+                                       k_scale, v_scale, kv_scales)
         if meta.num_prefill_tiles > 0:
             lib.paged_attention_prefill(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
                                         meta.query_start_loc, meta.prefill_tile_seq, meta.prefill_tile_q0,
-                                        meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale)
+                                        meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale, kv_scales)
         return out
     B = meta.num_decode + meta.num_prefill
+    if kv_scales is not None:
+        k_scale, v_scale = kv_scales[0], kv_scales[1]
     o = ref.paged_attention_ref(q.reshape(T, num_heads, head_dim), k_cache, v_cache, meta.block_tables[:B],
                                 meta.seq_lens[:B], meta.query_start_loc[:B + 1], scale, k_scale, v_scale)
     if out is not None:

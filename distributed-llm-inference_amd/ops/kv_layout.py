@@ -75,8 +75,11 @@ def write_kv_ref(k: torch.Tensor, v: torch.Tensor, slot_mapping: torch.Tensor,
     nchunk, ch = k_cache.shape[2], k_cache.shape[4]
     T, H, _D = k.shape
     if k_cache.dtype == torch.float8_e4m3fn:
-        k = (k.float() / k_scale).clamp(-448, 448)
-        v = (v.float() / v_scale).clamp(-448, 448)
+        # scales: python floats, or per-kv-head tensors [Hkv] (k, v are [T, Hkv, D])
+        ks = k_scale.float().view(1, -1, 1) if torch.is_tensor(k_scale) else k_scale
+        vs = v_scale.float().view(1, -1, 1) if torch.is_tensor(v_scale) else v_scale
+        k = (k.float() / ks).clamp(-448, 448)
+        v = (v.float() / vs).clamp(-448, 448)
     perm = v_slot_perm(bs).to(slot.device)
     kq, vq = k.reshape(T, H, nchunk, ch).to(k_cache.dtype), v.to(v_cache.dtype)
     if k_cache.dtype == torch.float8_e4m3fn:             # fp8 has no index_put: go through the bytes
@@ -93,8 +96,10 @@ def gather_kv_ref(k_cache: torch.Tensor, v_cache: torch.Tensor, block_ids: torch
     bs = v_cache.shape[-1]
     ids = block_ids.long()
     if k_cache.dtype == torch.float8_e4m3fn:             # fp8 has no gather: go through the bytes
-        kb = k_cache.view(torch.uint8)[ids].view(torch.float8_e4m3fn).float() * k_scale
-        vb = v_cache.view(torch.uint8)[ids].view(torch.float8_e4m3fn).float() * v_scale
+        ks = k_scale.float().view(1, -1, 1, 1, 1) if torch.is_tensor(k_scale) else k_scale
+        vs = v_scale.float().view(1, -1, 1, 1) if torch.is_tensor(v_scale) else v_scale
+        kb = k_cache.view(torch.uint8)[ids].view(torch.float8_e4m3fn).float() * ks
+        vb = v_cache.view(torch.uint8)[ids].view(torch.float8_e4m3fn).float() * vs
     else:
         kb = k_cache[ids].float() * k_scale              # [nb, H, nchunk, bs, ch]
         vb = v_cache[ids].float() * v_scale              # [nb, H, D, bs(slots)]

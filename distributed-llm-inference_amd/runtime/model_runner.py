@@ -416,6 +416,78 @@ class ModelRunner:
         self.graphs[bucket] = (g, meta, logits, comm)        # `logits`: the graph's own output buffer (self-test reads it)
         return g
 
+    # ------------------------------------------------------------------ fp8 KV calibration
+    @torch.inference_mode()
+    def calibrate_kv_scales(self, prompt_ids=None, num_tokens: int = 2048) -> dict:
+        """fp8 (e4m3) KV cache: set every layer's per-kv-head K and V scales from one warm-up prefill (amax / 448 with 20 %
+        head-room) instead of the unit scale — with unit scales small K/V values fall into e4m3's subnormals.  Runs the
+        normal forward over ``prompt_ids`` (default: ``num_tokens`` random ids) into scratch pages 0…; each attention
+        layer updates its scale tensor right before it writes the cache, so deeper layers are calibrated on activations
+        that already went through calibrated layers.  Under TP every rank calls this (each calibrates its own heads).
+        Scales live in device tensors that the kernels read at run time: calling it again later (e.g. on real prompts)
+        needs no re-capture of the decode graphs."""
+        from ..models.llama import Attention
+        attns = [m for m in self.model.modules() if isinstance(m, Attention)]
+        if self.kv_dtype != torch.float8_e4m3fn or not attns:
+            return {}
+        for a in attns:
+            if a.kv_scales is None:
+                a.enable_kv_scales(self.device)
+        T = min(num_tokens if prompt_ids is None else len(prompt_ids), self.max_T, self.cfg.sched.max_model_len - 1,
+                self.num_blocks * KV_BLOCK_SIZE)
+        T = max(T // 16 * 16, 16) if T >= 16 else T
+        if prompt_ids is None:
+            ids = np.random.default_rng(1234).integers(3, self.cfg.model.vocab_size, size=T)
+        else:
+            ids = np.asarray(prompt_ids[:T])
+        nb = (T + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+        nv = self.nv
+        self.n_input[:T] = ids
+        self.n_pos[:T] = np.arange(T)
+        self.n_slot[:T] = np.arange(T)                       # pages 0 … nb-1, in order
+        self.n_bt[0, :nb] = np.arange(nb)
+        self.n_seq_lens[0] = T
+        self.n_qsl[:2] = (0, T)
+        ts, t0 = ops.build_prefill_tiles(np.array([T], dtype=np.int32), 0, self.tile_tokens)
+        nv["tile_seq"][:len(ts)] = ts
+        nv["tile_q0"][:len(ts)] = t0
+        self._copy_in()
+        meta = self._meta(1, T, 0, 0, 1, len(ts))
+        for a in attns:
+            a.calibrating, a._calibrated = True, False
+        try:
+            self.model(self.dv["input"][:T], meta, self.kv_caches)
+        finally:
+            for a in attns:
+                a.calibrating = False
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        sc = torch.stack([a.kv_scales for a in attns]).float().cpu()          # [layers, 2, Hkv]
+        self.selftest["fp8_kv_scales"] = {"tokens": int(T), "k_scale_min": float(sc[:, 0].min()), "k_scale_max": float(sc[:, 0].max()),
+                                          "v_scale_min": float(sc[:, 1].min()), "v_scale_max": float(sc[:, 1].max())}
+        return self.selftest["fp8_kv_scales"]
+
+    @torch.inference_mode()
+    def prefill_logits(self, ids) -> torch.Tensor:
+        """Test / tooling helper: logits ``[T, V]`` (fp32) of one prompt prefilled into scratch pages 0…, every position
+        attending through the paged cache (so the KV-cache dtype and scales are in the loop)."""
+        T = len(ids)
+        assert T <= self.max_T and T < self.cfg.sched.max_model_len and T <= self.num_blocks * KV_BLOCK_SIZE
+        nb = (T + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+        nv = self.nv
+        self.n_input[:T] = np.asarray(ids)
+        self.n_pos[:T] = np.arange(T)
+        self.n_slot[:T] = np.arange(T)
+        self.n_bt[0, :nb] = np.arange(nb)
+        self.n_seq_lens[0] = T
+        self.n_qsl[:2] = (0, T)
+        ts, t0 = ops.build_prefill_tiles(np.array([T], dtype=np.int32), 0, self.tile_tokens)
+        nv["tile_seq"][:len(ts)] = ts
+        nv["tile_q0"][:len(ts)] = t0
+        self._copy_in()
+        h = self.model(self.dv["input"][:T], self._meta(1, T, 0, 0, 1, len(ts)), self.kv_caches)
+        return self.model.compute_logits(h).float()
+
     # ------------------------------------------------------------------ start-up self-tests
     def _stage_synthetic_decode(self, B: int, ctx_len: int = 24):
         """A deterministic decode batch of ``B`` sequences (one page each) in the static buffers — the same on every

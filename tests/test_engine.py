@@ -405,3 +405,29 @@ def test_hf_stream_decoder_is_incremental_and_exact(tmp_path):
     out = "".join(dec.step(i) for i in ids) + dec.flush()
     assert out == text
     assert max(calls) <= 32, "a decode call must never see more than a short window of ids"
+
+
+def test_fp8_kv_scale_calibration_matters_when_kv_values_are_small():
+    """tiny-llama K/V values are ≈ 0.1: at unit scale e4m3 stores them in its subnormals and greedy decoding falls apart;
+    with the warm-up calibration (per-layer, per-kv-head amax / 448) it follows the exact-KV run."""
+    from dli_amd.config import CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config
+    from dli_amd.engine.engine import LLMEngine
+
+    def run(kv, calib=True):
+        cfg = EngineConfig(model=get_model_config("tiny-llama"),
+                           cache=CacheConfig(num_blocks=64, kv_dtype=kv, calibrate_fp8_scales=calib),
+                           sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=256, max_model_len=256),
+                           device="cpu", use_hip_graphs=False)
+        eng = LLMEngine(cfg)
+        eng.warmup()
+        rng = np.random.default_rng(0)
+        prompts = [rng.integers(3, 500, size=n).tolist() for n in (40, 100, 7)]
+        return eng.generate(None, SamplingParams(temperature=0.0, max_tokens=12, ignore_eos=True), prompt_ids=prompts), eng
+
+    agree = lambda x, y: float(np.mean([np.mean(np.array(p) == np.array(q)) for p, q in zip(x, y)]))
+    exact, _ = run("auto")
+    cal, eng = run("fp8")
+    unit, _ = run("fp8", calib=False)
+    st = eng.runner.selftest["fp8_kv_scales"]
+    assert 0 < st["k_scale_max"] < 0.05 and 0 < st["v_scale_max"] < 0.05          # far below the unit scale
+    assert agree(exact, cal) >= 0.8 and agree(exact, cal) > agree(exact, unit) + 0.3
