@@ -91,6 +91,8 @@ def parse(argv=None):
     ap.add_argument("--sweep", action="store_true", help="SLO frontier instead of the fixed-load run")
     ap.add_argument("--sweep-qps", default="", help="comma-separated offered loads per replica (default: around the model's rate)")
     ap.add_argument("--sweep-window", type=float, default=30.0)
+    ap.add_argument("--sweep-rows", default="relaxed,interactive", help="SLO rows the sweep covers")
+    ap.add_argument("--sweep-ramp", type=float, default=20.0, help="untimed replay before each sweep point's window")
     ap.add_argument("--dump", default="", help="write per-request records of rank 0 to this JSON file")
     return ap.parse_args(argv)
 
@@ -438,6 +440,8 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
     sc = eng.scheduler.cfg
     rows = {}
     for row_name, slo in slo_rows.items():
+        if row_name not in args.sweep_rows.split(","):
+            continue
         sc.ttft_slo = None if args.fcfs else slo[0]
         sc.max_queue_delay = None if args.fcfs else 4.0 * slo[0]
         sc.tpot_slo = slo[1] if (args.tpot_control or row_name == "interactive") else None
@@ -445,7 +449,7 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
         eng.scheduler.step_ema = None
         out = []
         for pi, q in enumerate(pts):
-            ramp, win, tail = min(args.ramp_seconds, 20.0), args.sweep_window, 12.0
+            ramp, win, tail = args.sweep_ramp, args.sweep_window, 12.0
             stamps, n_in, n_out = make_share(args, mcfg, layout, q, ramp + win + tail + 30.0, args.seed + 101 + pi)
             rp = Replay(eng, mcfg.vocab_size, stamps, n_in, n_out, args.seed * 1000 + layout.replica + 7 * pi)
             rp.tag = f"{row_name[0]}{pi}"
@@ -521,7 +525,7 @@ def sweep_line(args, allstats, layout, qps):
         "data": "synthetic (BurstGPT-like Gamma arrivals + log-normal lengths clamped to 1024/1024, random token ids, "
                 "random-init weights); attainment over the requests that ARRIVED in each point's window",
         "config": {"model": args.model, "global_batch": args.max_num_seqs * layout.dp, "seq_len": 2048,
-                   "parallelism": par, "kv_dtype": args.kv_dtype, "window_s": args.sweep_window,
+                   "parallelism": par, "kv_dtype": args.kv_dtype, "window_s": args.sweep_window, "ramp_s": args.sweep_ramp,
                    "tpot_control": "interactive row" if not args.tpot_control else "both rows"},
         "frontier": frontier, "sweep": table,
     }

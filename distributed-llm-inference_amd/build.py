@@ -52,11 +52,19 @@ def build_runtime(verbose: bool = False) -> str:
     src = os.path.join(CSRC, "runtime", "block_manager.cpp")
     if _newer([src, os.path.join(CSRC, "runtime", "block_manager.h")], RUNTIME_SO):
         cxx = os.environ.get("CXX", "g++")
+        # several processes may get here at once on a fresh checkout (TP workers, router replicas import the module
+        # concurrently): each links into its own temp file and renames it into place — nobody can import a half-written .so
+        tmp = f"{RUNTIME_SO}.{os.getpid()}.tmp"
         cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-               "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", RUNTIME_SO]
+               "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"], src, "-o", tmp]
         if verbose:
             print(" ".join(cmd))
-        _run(cmd)
+        try:
+            _run(cmd)
+            os.replace(tmp, RUNTIME_SO)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return RUNTIME_SO
 
 
@@ -104,7 +112,13 @@ def build_kernels(verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(len(jobs), int(os.environ.get("MAX_JOBS", "8")))) as pool:
             list(pool.map(one, jobs))
     if jobs or _newer(objs, KERNELS_SO):
-        one([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + libs + ["-o", KERNELS_SO])
+        tmp = f"{KERNELS_SO}.{os.getpid()}.tmp"
+        try:
+            one([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + libs + ["-o", tmp])
+            os.replace(tmp, KERNELS_SO)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return KERNELS_SO
 
 

@@ -222,12 +222,15 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   }
   lsum = group_sum(lsum);
 
-  // ---- merge the 4 waves through LDS: [wave][G][128] fp32 + [wave][G] (m, l)
+  // ---- merge the 4 waves through LDS: [wave][G][128 + 4] fp32 + [wave][G] (m, l).  Rows are padded by one 16-byte
+  // slot: the G active lanes of a ds_write_b128 lane group hold the same d range of G different rows, and with
+  // 512-byte rows they would all start on bank 0 (4-way conflict: 0.46 conflict cycles per LDS cycle in round 1).
+  constexpr int HDP = HD + 4;
   float* sm_o = smem;
-  float* sm_m = smem + 4 * G * HD;
+  float* sm_m = smem + 4 * G * HDP;
   float* sm_l = sm_m + 4 * G;
   if (col < G) {
-    float* dst = sm_o + (wave * G + col) * HD + 4 * g;
+    float* dst = sm_o + (wave * G + col) * HDP + 4 * g;
 #pragma unroll
     for (int n = 0; n < 8; ++n) *reinterpret_cast<f32x4*>(dst + 16 * n) = o[n];
     if (g == 0) { sm_m[wave * G + col] = m; sm_l[wave * G + col] = lsum; }
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float f = fast_exp2(sm_m[w * G + head] - M);
-      num += f * sm_o[(w * G + head) * HD + d];
+      num += f * sm_o[(w * G + head) * HDP + d];
       den += f * sm_l[w * G + head];
     }
     const int qh = kvh * G + head;
@@ -482,7 +485,7 @@ void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, c
   const int G = Hq / Hkv;
   if (kv_scales != nullptr) k_scale = v_scale = 1.f;        // the kernels read the per-head values themselves
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
-  const size_t lds = (size_t)(4 * G * HD + 8 * G) * sizeof(float);
+  const size_t lds = (size_t)(4 * G * (HD + 4) + 8 * G) * sizeof(float);
   dim3 grid(num_seqs, Hkv, num_splits);
   if (kv_fp8)
     hipLaunchKernelGGL(paged_decode_kernel<true>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
