@@ -433,7 +433,10 @@ def fixed_line(args, allstats, layout, slo, qps, mcfg):
 # ------------------------------------------------------------------------------------------ SLO frontier
 def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
     """For each SLO row: replay at increasing offered load (fresh trace per point, ramp + window in real time) and
-    record attainment over the requests that ARRIVED in the window's first part (so each had time to finish)."""
+    record attainment over the requests that ARRIVED in the window (a tail lets them finish; the ones still generating
+    are judged on their progress so far).  A point only counts towards the frontier if it is a steady state:
+    completions per second inside the window ≥ 95 % of arrivals per second (otherwise the in-flight population is still
+    growing and the window has not seen the TPOT that load ends up with)."""
     import numpy as np
     pts = [float(x) for x in args.sweep_qps.split(",") if x] or \
         [round(qps * f, 1) for f in (0.25, 0.4, 0.55, 0.7, 0.8, 0.9, 1.0, 1.1)]
@@ -478,9 +481,18 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
                 run = (r.last_token_time - r.first_token_time) / max(r.num_output - r.pending - 1, 1)
                 good_open += int(r.first_token_time - r.arrival <= slo[0] and run <= slo[1])
             shed_cohort = len(cohort_idx) - len(fin) - sum(1 for r in rp.live.values() if lo <= r.arrival < hi)
+            # is the point a steady state?  requests in the system (queued or running) at the window's two ends, and
+            # completions per second inside it: a point whose population still grows has not reached its TPOT yet
+            served = list(rp.done) + list(rp.live.values())
+
+            def in_system(t):
+                return sum(1 for r in served if r.arrival <= t) - sum(1 for r in rp.done if r.finish_time <= t)
+            pop_lo, pop_hi = in_system(lo), in_system(hi)
+            done_in_win = sum(1 for r in rp.done if lo <= r.finish_time < hi)
             res = {"offered_qps": q * layout.dp, "cohort": len(fin) + n_open + max(shed_cohort, 0), "finished": len(fin),
                    "good": int(ok.sum()) + good_open, "still_running": n_open, "shed": max(shed_cohort, 0),
-                   "ttft": ttft.tolist(), "tpot": tpot.tolist(), "window_s": win}
+                   "ttft": ttft.tolist(), "tpot": tpot.tolist(), "window_s": win,
+                   "in_system_at_window_start": pop_lo, "in_system_at_window_end": pop_hi, "finished_in_window": done_in_win}
             out.append(res)
             rp.drain()
             if layout.rank == 0:
@@ -509,10 +521,17 @@ def sweep_line(args, allstats, layout, qps):
                         "still_running_at_end": sum(p.get("still_running", 0) for p in ps), "shed": sum(p.get("shed", 0) for p in ps),
                         "attainment": round(good / max(cohort, 1), 4),
                         "goodput_req_per_s": round(good / ps[0]["window_s"], 3),
+                        "arrivals_per_s": round(cohort / ps[0]["window_s"], 3),
+                        "finished_per_s": round(sum(p["finished_in_window"] for p in ps) / ps[0]["window_s"], 3),
+                        "in_system_at_window_start": sum(p["in_system_at_window_start"] for p in ps),
+                        "in_system_at_window_end": sum(p["in_system_at_window_end"] for p in ps),
                         "ttft_p50_s": pct(ttft, 50), "ttft_p99_s": pct(ttft, 99),
                         "tpot_p50_s": pct(tpot, 50), "tpot_p99_s": pct(tpot, 99)})
+        for t in tab:
+            # steady: completions keep up with arrivals (≥ 95 %), i.e. the in-flight population is not still building up
+            t["steady"] = bool(t["finished_per_s"] >= 0.95 * t["arrivals_per_s"])
         table[row_name] = tab
-        okp = [t for t in tab if t["attainment"] >= 0.9]
+        okp = [t for t in tab if t["attainment"] >= 0.9 and t["steady"]]
         frontier[row_name] = max(okp, key=lambda t: t["offered_qps"]) if okp else None
     slo = SLOS.get(args.model, SLOS["llama3-8b"])
     best = frontier.get(args.slo)

@@ -64,3 +64,21 @@ def test_gpus_must_match_world():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "cpu"], capture_output=True,
                        text=True, timeout=60, env=env, cwd=ROOT)
     assert p.returncode != 0 and "one rank per GPU" in p.stderr
+
+
+def test_sweep_reports_frontier_with_steady_state_check():
+    """`--sweep`: one JSON line with, per SLO row, the swept points (attainment over the window's arrivals, arrivals and
+    completions per second, population at both ends of the window) and the frontier = largest STEADY point ≥ 90 %."""
+    p, lines = run_bench(["--model", "tiny-llama", "--sweep", "--sweep-qps", "2,4", "--sweep-window", "3", "--sweep-ramp", "1",
+                          "--sweep-rows", "relaxed"])
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("max_offered_qps_with_90pct_slo_attainment") and list(d["sweep"]) == ["relaxed"]
+    pts = d["sweep"]["relaxed"]
+    assert [t["offered_qps"] for t in pts] == [2.0, 4.0]
+    for t in pts:
+        assert {"arrivals", "good", "attainment", "arrivals_per_s", "finished_per_s", "in_system_at_window_start",
+                "in_system_at_window_end", "steady", "shed", "still_running_at_end"} <= set(t)
+        assert t["good"] <= t["arrivals"]
+    steady_ok = [t for t in pts if t["steady"] and t["attainment"] >= 0.9]
+    assert d["value"] == (max(t["offered_qps"] for t in steady_ok) if steady_ok else 0.0)
