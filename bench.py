@@ -494,7 +494,10 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
                    "ttft": ttft.tolist(), "tpot": tpot.tolist(), "window_s": win,
                    "in_system_at_window_start": pop_lo, "in_system_at_window_end": pop_hi, "finished_in_window": done_in_win}
             out.append(res)
-            rp.drain()
+            # no drain between the points of a row: loads are swept upwards and the next point starts from this one's
+            # population (a point that starts from an empty engine needs 2–3 request lifetimes of ramp to be steady);
+            # what is left of this point's requests finishes inside the engine, untracked
+            rp.live.clear()
             if layout.rank == 0:
                 att = res["good"] / max(res["cohort"], 1)
                 print(f"[sweep] {row_name} qps/replica {q:g}: attainment {att:.3f} "
@@ -503,6 +506,7 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
             if res["good"] / max(res["cohort"], 1) < 0.5:
                 break                                        # far past the frontier: higher loads only take time
         rows[row_name] = out
+        rp.drain()                                           # rows differ in scheduler settings: start the next one empty
     return {"replica": layout.replica, "rows": rows}
 
 

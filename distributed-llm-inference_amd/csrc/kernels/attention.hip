@@ -287,9 +287,8 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
 //
 // Unlike decode, all four waves of a tile walk the SAME pages, so the K and V pages are staged through
 // LDS: the block copies each 32-token page (K + V, 16 KB bf16 / 8 KB fp8) once, 16 bytes per lane,
-// into one of two LDS buffers while the MFMAs of the previous page run (global → registers before the
-// math, registers → LDS after it, one barrier per page), and every wave reads its fragments with
-// ds_read_b128.  That cuts the vector-memory traffic of the tile 4× (it was the limiter: 64 KB through
+// into a ring of three LDS buffers by LDS-DMA, two pages ahead of the math (one barrier per page, counted
+// vmcnt), and every wave reads its fragments with ds_read_b128.  That cuts the vector-memory traffic of the tile 4× (it was the limiter: 64 KB through
 // the texture path per page against 512 MFMA cycles).  The page keeps its global layout in LDS except
 // that the four 16-byte slots of every 64-byte row are permuted by the row (slot ^ h[(row >> 2) & 3],
 // h = {0,2,3,1}): the 16 lanes the hardware serves together for a ds_read_b128 — {0–3, 12–15, 20–27}
@@ -311,7 +310,9 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   constexpr int ESZ = KV8 ? 1 : 2;
   constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;            // one K (or V) page of one kv head
   constexpr int NCH = PAGE_BYTES / (16 * 256);            // 16-byte chunks per thread and operand: 2 (bf16) / 1 (fp8)
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * PAGE_BYTES];   // [buffer][K | V]
+  constexpr int NSTAGE = 3;                               // LDS ring: page b is read while b+1 and b+2 are in flight
+  constexpr int NDMA = 2 * NCH;                           // LDS-DMA instructions per thread and page
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * PAGE_BYTES];   // [stage][K | V]
 
   const int kvh = blockIdx.y;
   const int G = Hq / Hkv;                      // 1, 2, 4 or 8 (checked on the host)
@@ -389,15 +390,25 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   }
   const int lane_off = col * 64 + ((g ^ slot_swizzle(col)) << 4);           // this lane's 16 bytes of a 16-row group
 
+  // Prefetch distance two pages: one page of math (≈ 1 k cycles) is shorter than an HBM round trip under load, so
+  // with a single page in flight every iteration ended in a full drain.  vmcnt is counted: "≤ NDMA outstanding" means
+  // everything but the newest page has landed; the drain only happens on the last page.
   DLI_STAGE(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nblk > 1) {
+    DLI_STAGE(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
+  int st = 0;                                             // stage of page b
   for (int b = 0; b < nblk; ++b) {
-    const bool more = b + 1 < nblk;
-    // next page → the buffer read during page b-1 (every wave is past that barrier); in flight under this page's math
-    if (more) DLI_STAGE(b + 1, (b + 1) & 1);
+    // page b+2 → the stage read during page b-1 (every wave is past that barrier)
+    const bool ahead = b + 2 < nblk;
+    const int st2 = st == 0 ? NSTAGE - 1 : st - 1;        // (b + 2) % 3 == (b - 1) % 3
+    if (ahead) DLI_STAGE(b + 2, st2);
     if (b < my_nblk) {
-      const char* kb = smem + (b & 1) * 2 * PAGE_BYTES;
+      const char* kb = smem + st * 2 * PAGE_BYTES;
       const char* vb = kb + PAGE_BYTES;
       const bool need_mask = b * 32 + 31 > first_tok;   // some query of this wave sits before the page end
       f32x4 s[2][2];
@@ -455,8 +466,11 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
         for (int i = 0; i < 2; ++i) o[i][n] = mfma16(vf, pb[i], o[i][n]);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of the next page has landed in LDS
+    // my share of page b+1 has landed in LDS (page b+2 may still be in flight)
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    st = st == NSTAGE - 1 ? 0 : st + 1;
   }
 
 #pragma unroll
