@@ -434,9 +434,8 @@ def fixed_line(args, allstats, layout, slo, qps, mcfg):
 def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
     """For each SLO row: replay at increasing offered load (fresh trace per point, ramp + window in real time) and
     record attainment over the requests that ARRIVED in the window (a tail lets them finish; the ones still generating
-    are judged on their progress so far).  A point only counts towards the frontier if it is a steady state:
-    completions per second inside the window ≥ 95 % of arrivals per second (otherwise the in-flight population is still
-    growing and the window has not seen the TPOT that load ends up with)."""
+    are judged on their progress so far).  Loads are swept upwards without draining the engine in between.  A point
+    only counts towards the frontier if it is a steady state (``mark_steady``)."""
     import numpy as np
     pts = [float(x) for x in args.sweep_qps.split(",") if x] or \
         [round(qps * f, 1) for f in (0.25, 0.4, 0.55, 0.7, 0.8, 0.9, 1.0, 1.1)]
@@ -510,6 +509,15 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
     return {"replica": layout.replica, "rows": rows}
 
 
+def mark_steady(t, window_s):
+    """A sweep point is a steady state if the number of requests in the system (queued + running; shed ones have left)
+    grows by less than 10 % of the window's arrivals: below that the point's TTFT / TPOT are the ones this load ends up
+    with, above it the backlog is still building and the window has not seen the latencies to come."""
+    t["population_growth_per_s"] = round((t["in_system_at_window_end"] - t["in_system_at_window_start"]) / window_s, 3)
+    t["steady"] = bool(t["population_growth_per_s"] < 0.10 * t["arrivals_per_s"])
+    return t
+
+
 def sweep_line(args, allstats, layout, qps):
     import numpy as np
     table, frontier = {}, {}
@@ -532,8 +540,7 @@ def sweep_line(args, allstats, layout, qps):
                         "ttft_p50_s": pct(ttft, 50), "ttft_p99_s": pct(ttft, 99),
                         "tpot_p50_s": pct(tpot, 50), "tpot_p99_s": pct(tpot, 99)})
         for t in tab:
-            # steady: completions keep up with arrivals (≥ 95 %), i.e. the in-flight population is not still building up
-            t["steady"] = bool(t["finished_per_s"] >= 0.95 * t["arrivals_per_s"])
+            mark_steady(t, ps[0]["window_s"])
         table[row_name] = tab
         okp = [t for t in tab if t["attainment"] >= 0.9 and t["steady"]]
         frontier[row_name] = max(okp, key=lambda t: t["offered_qps"]) if okp else None
