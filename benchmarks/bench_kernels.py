@@ -223,13 +223,18 @@ def bench_gemm256(quick):
     import torch.nn.functional as F
     lib = ops.hip()
     shapes = [("8b_gate_up", 28672, 4096, True), ("70b_tp8_gate_up", 7168, 8192, True), ("8b_qkv", 6144, 4096, False),
-              ("8b_down", 4096, 14336, False), ("70b_tp8_down", 8192, 3584, False)]
+              ("8b_o", 4096, 4096, False), ("8b_down", 4096, 14336, False), ("70b_tp8_down", 8192, 3584, False)]
+    ms_env = os.environ.get("DLI_BENCH_GEMM_MS")          # e.g. "2304,2816,3328": the step sizes the serving loop produces
+    ms = tuple(int(v) for v in ms_env.split(",")) if ms_env else (512, 1024, 2048, 4096, 8192)
+    only_shapes = os.environ.get("DLI_BENCH_GEMM_SHAPES")
+    if only_shapes:
+        shapes = [sh for sh in shapes if sh[0] in only_shapes.split(",")]
     for name, N, K, swiglu in (shapes[:2] if quick else shapes):
         if not swiglu and N % 256:
             continue
         copies = max(2, -(-(600 << 20) // (N * K * 2)))
         ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(copies)]
-        for M in ((4096,) if quick else (512, 1024, 2048, 4096, 8192)):
+        for M in ((4096,) if quick else ms):
             x = torch.randn(M, K, device=DEV).bfloat16()
             state = {"i": 0}
 
@@ -250,7 +255,7 @@ def bench_gemm256(quick):
                    library_TFLOPs=round(fl / t_gemm / 1e12, 1), speedup_vs_library_path=round(t_lib / t_new, 3))
         del ws
     H, I, E = 4096, 14336, 8
-    for T, El in ([(4096, 8)] if quick else [(1024, 8), (2048, 8), (4096, 8), (8192, 8), (4096, 1)]):
+    for T, El in ([(4096, 8)] if quick else [] if only_shapes else [(1024, 8), (2048, 8), (4096, 8), (8192, 8), (4096, 1)]):
         x = torch.randn(T, H, device=DEV).bfloat16()
         logits = torch.randn(T, E, device=DEV).bfloat16()
         w13 = (torch.randn(El, 2 * I, H, device=DEV) * 0.02).bfloat16()
