@@ -38,7 +38,10 @@ __device__ __forceinline__ float fp8_to_f(uint8_t v) {
   return __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(v), 0);
 }
 __device__ __forceinline__ uint8_t f_to_fp8(float f) {
-  // v_cvt_pk_fp8_f32 saturates to ±448 on gfx950 (OCP, FP8 saturation mode is the default)
+  // Clamp explicitly (one v_med3_f32): without it a value past ±448 — an activation outlier beyond the calibrated
+  // scale's head-room — converts to the e4m3 NaN pattern, and one NaN key poisons every later softmax of its sequence.
+  // fmaxf / fminf drop a NaN input as well (→ −448).
+  f = fminf(fmaxf(f, -448.f), 448.f);
   int packed = __builtin_amdgcn_cvt_pk_fp8_f32(f, f, 0, false);
   return static_cast<uint8_t>(packed & 0xff);
 }

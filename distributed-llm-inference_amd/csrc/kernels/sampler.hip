@@ -50,6 +50,10 @@ struct ArgMax {
   float v;
   int i;
 };
+
+// A row of NaN logits never beats the initial candidate and leaves its out-of-range index behind: the next step would
+// use it as an embedding row (a GPU fault).  Such a row yields token 0 instead; the NaN itself is the caller's bug.
+__device__ __forceinline__ int valid_token(int i, int V) { return (unsigned)i < (unsigned)V ? i : 0; }
 __device__ __forceinline__ ArgMax amax(ArgMax a, ArgMax b) {
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const T* __restrict__ logit
     ArgMax a{-3.0e38f, 0x7fffffff};
     for (int i = threadIdx.x; i < V; i += SNT) a = amax(a, ArgMax{ld<T>(row, i), i});
     a = block_argmax(a, sv, si);
-    if (threadIdx.x == 0) out[b] = a.i;
+    if (threadIdx.x == 0) out[b] = valid_token(a.i, V);
     return;
   }
 
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(SNT) void sample_kernel(const T* __restrict__ logit
     }
   }
   a = block_argmax(a, sv, si);
-  if (threadIdx.x == 0) out[b] = a.i;
+  if (threadIdx.x == 0) out[b] = valid_token(a.i, V);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(SNT) void sample_bf16_kernel(const uint16_t* __rest
       for (int e = 0; e < 8; ++e)
         a = amax(a, ArgMax{bf2f((uint16_t)half_of(regs[c], e)), (c * SNT + (int)threadIdx.x) * 8 + e});
     a = block_argmax(a, sv, si);
-    if (threadIdx.x == 0) out[b] = a.i;
+    if (threadIdx.x == 0) out[b] = valid_token(a.i, V);
     return;
   }
 
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(SNT) void sample_bf16_kernel(const uint16_t* __rest
     }
   }
   a = block_argmax(a, sv, si);
-  if (threadIdx.x == 0) out[b] = a.i;
+  if (threadIdx.x == 0) out[b] = valid_token(a.i, V);
 }
 
 void launch_sample(const void* logits, bool logits_fp32, int64_t row_stride, int B, int V, const float* temperature,

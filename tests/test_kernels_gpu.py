@@ -97,6 +97,24 @@ def test_rope_and_cache(Hq, Hkv, kv_dtype, layout):
         torch.testing.assert_close(vc.float(), vc_ref.float(), rtol=0.13, atol=0.02)
 
 
+def test_fp8_cache_write_saturates_instead_of_nan():
+    """Values past scale × 448 (activation outliers beyond the calibrated head-room) must store ±448, never the e4m3
+    NaN pattern: one NaN key poisons every later softmax of its sequence (found with the 80 req/s fp8 bench)."""
+    Hq, Hkv, T = 4, 2, 8
+    qkv = _bf(T, (Hq + 2 * Hkv) * 128, seed=3) * 100.0            # K, V up to ≈ ±400 with scales 0.05 → ±8000 / scale
+    qkv[0, Hq * 128:] = float("inf")
+    qkv[1, Hq * 128:] = float("nan")
+    pos = torch.zeros(T, dtype=torch.int32, device=DEV)
+    slots = torch.arange(T, dtype=torch.int32, device=DEV)
+    cs = ref.build_cos_sin_cache(16, 128, 500000.0, DEV)
+    kc, vc = _caches(2, Hkv, torch.float8_e4m3fn)
+    ops.rope_and_cache(qkv, pos, cs, slots, kc, vc, Hq, Hkv, 128, 0.05, 0.05)
+    for c in (kc, vc):
+        b = c.view(torch.uint8)
+        assert not ((b & 0x7F) == 0x7F).any(), "NaN pattern in the fp8 cache"
+        assert torch.isfinite(c.float()).all() and c.float().abs().max() == 448.0
+
+
 def _fill_cache(Hq, Hkv, seq_lens, kv_dtype, seed=0, scales=(1.0, 1.0)):
     """Random K/V for every sequence written through the reference packer; returns caches + tables."""
     g = torch.Generator().manual_seed(seed)
@@ -212,6 +230,22 @@ def test_sampler_matches_reference_with_shared_noise(V, dtype):
         assert (got[[0, 7]] == logits.float().argmax(-1)[[0, 7]]).all()          # greedy rows
         assert logits[8, got[8]] == logits[8].max()                                 # top_k = 1 (bf16 ties allowed)
     assert agree >= rounds * B - 2, f"only {agree}/{rounds * B} draws agree with the reference"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_sampler_nan_row_yields_a_valid_token(dtype):
+    """A NaN row (a bug upstream) must not turn into an out-of-range token id: the next step embeds it."""
+    B, V = 6, 128256
+    logits = torch.randn(B, V, device=DEV).to(dtype)
+    logits[1] = float("nan")
+    logits[4] = float("nan")
+    temp = torch.tensor([0.0, 0.0, 0.7, 1.0, 0.7, 1.0], device=DEV)
+    top_p = torch.tensor([1.0, 1.0, 1.0, 0.9, 0.9, 1.0], device=DEV)
+    top_k = torch.tensor([0, 0, 0, 40, 40, 0], dtype=torch.int32, device=DEV)
+    seeds = torch.arange(B, dtype=torch.int64, device=DEV)
+    steps = torch.zeros(B, dtype=torch.int64, device=DEV)
+    got = ops.sample(logits, temp, top_p, top_k, seeds, steps)
+    assert ((got >= 0) & (got < V)).all(), got
 
 
 def test_sampler_philox_distribution_and_determinism():
