@@ -385,11 +385,15 @@ def spawn_replicas(n: int, base_port: int, server_args: list[str], gpus: bool = 
     return procs
 
 
-async def wait_ready(urls: list[str], timeout: float = 1800.0):
+async def wait_ready(urls: list[str], timeout: float = 1800.0, procs: list | None = None):
+    """Block until every replica answers ``/health``.  A spawned replica that EXITS while we wait (out of memory, bad
+    arguments) fails the start-up at once instead of leaving the caller polling a router without replicas."""
     t0 = time.time()
     async with aiohttp.ClientSession() as s:
-        for u in urls:
+        for i, u in enumerate(urls):
             while True:
+                if procs is not None and procs[i].poll() is not None:
+                    raise RuntimeError(f"replica {u} exited with code {procs[i].returncode} during start-up")
                 try:
                     async with s.get(u + "/health", timeout=aiohttp.ClientTimeout(total=2)) as r:
                         if r.status == 200:
@@ -417,7 +421,12 @@ def main(argv=None):
     if a.spawn:
         urls = [f"http://127.0.0.1:{a.replica_base_port + i}" for i in range(a.spawn)]
         procs = spawn_replicas(a.spawn, a.replica_base_port, server_args, gpus=not a.cpu)
-        asyncio.run(wait_ready(urls))
+        try:
+            asyncio.run(wait_ready(urls, procs=procs))
+        except BaseException:
+            for p in procs:
+                p.terminate()
+            raise
     else:
         urls = [u for u in a.replicas.split(",") if u]
     if not urls:

@@ -225,3 +225,16 @@ def test_router_retries_a_shedding_replica_and_relays_503_when_all_shed():
             await r.cleanup()
 
     asyncio.run(body())
+
+
+def test_spawned_replica_that_dies_fails_the_router_start():
+    """`--spawn N` with replicas that exit during start-up (here: an unknown model) must end the router with an error
+    instead of serving a port without replicas (seen on the GPU box: two replicas sized their KV cache from the same
+    free memory, both died, the router kept waiting)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "dli_amd.router.router", "--spawn", "2", "--cpu", "--port", "0",
+                        "--replica-base-port", "18740", "--model", "no-such-model", "--device", "cpu"],
+                       capture_output=True, text=True, timeout=120, cwd=root,
+                       env=dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", "")))
+    assert p.returncode != 0 and "exited with code" in p.stderr
