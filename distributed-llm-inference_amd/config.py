@@ -83,6 +83,13 @@ MODEL_PRESETS: dict[str, ModelConfig] = {
                                 intermediate_size=256, num_layers=2, num_heads=8, num_kv_heads=2,
                                 head_dim=16, max_position=512, num_experts=4, top_k_experts=2,
                                 dtype="float32"),
+    # 8 KV heads / 8 experts: the world-size-8 layouts of BASELINE configs 4 and 5 (TP = 8, EP = 8) on CPU
+    "tiny-llama-8kv": ModelConfig(name="tiny-llama-8kv", vocab_size=512, hidden_size=128, intermediate_size=256,
+                                  num_layers=2, num_heads=16, num_kv_heads=8, head_dim=8, max_position=512,
+                                  dtype="float32"),
+    "tiny-mixtral-8e": ModelConfig(name="tiny-mixtral-8e", arch="mixtral", vocab_size=512, hidden_size=128,
+                                   intermediate_size=256, num_layers=2, num_heads=16, num_kv_heads=8, head_dim=8,
+                                   max_position=512, num_experts=8, top_k_experts=2, dtype="float32"),
     "tiny-opt": ModelConfig(name="tiny-opt", arch="opt", vocab_size=512, hidden_size=64,
                             intermediate_size=128, num_layers=2, num_heads=4, num_kv_heads=4,
                             head_dim=16, max_position=512, pos_offset=2, tie_embeddings=True,

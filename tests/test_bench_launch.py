@@ -82,3 +82,21 @@ def test_sweep_reports_frontier_with_steady_state_check():
         assert t["good"] <= t["arrivals"]
     steady_ok = [t for t in pts if t["steady"] and t["attainment"] >= 0.9]
     assert d["value"] == (max(t["offered_qps"] for t in steady_ok) if steady_ok else 0.0)
+
+
+@pytest.mark.parametrize("extra,par", [
+    (["--gpus", "8", "--model", "tiny-llama"], "dp8"),
+    (["--gpus", "8", "--tp", "8", "--model", "tiny-llama-8kv"], "tp8"),
+    (["--gpus", "8", "--tp", "8", "--ep", "8", "--model", "tiny-mixtral-8e", "--ep-a2a-min-tokens", "64"], "tp8+ep8"),
+])
+def test_world_size_8_layouts(extra, par):
+    """The three 8-rank layouts the driver runs on the 8-GPU node (BASELINE configs 3, 4, 5), on CPU with gloo: rank
+    grouping, driver election, one expert per rank, all-to-all over 8 ranks, one JSON line."""
+    p, lines = run_bench(extra, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == par and d["requests_finished"] > 0
+    assert len(d["device_ids"]) == 8
+    if "ep8" in par:
+        assert d["comm_per_step"]["a2a_calls"] > 0      # prefill-sized steps dispatched by all-to-all over 8 ranks
