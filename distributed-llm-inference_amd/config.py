@@ -73,6 +73,12 @@ MODEL_PRESETS: dict[str, ModelConfig] = {
     # TP-shardable D=128 shapes for the GPU TP tests (2 KV heads, 4 experts)
     "tiny-llama-tp": ModelConfig(name="tiny-llama-tp", vocab_size=1024, hidden_size=512, intermediate_size=1024,
                                  num_layers=2, num_heads=8, num_kv_heads=2, head_dim=128, max_position=4096),
+    # 8 KV heads / 8 experts at D = 128: TP = 8 / EP = 8 rehearsals with 8 ranks sharing one GPU
+    "tiny-llama-tp8": ModelConfig(name="tiny-llama-tp8", vocab_size=1024, hidden_size=1024, intermediate_size=2048,
+                                  num_layers=2, num_heads=8, num_kv_heads=8, head_dim=128, max_position=4096),
+    "tiny-mixtral-tp8": ModelConfig(name="tiny-mixtral-tp8", arch="mixtral", vocab_size=1024, hidden_size=1024,
+                                    intermediate_size=2048, num_layers=2, num_heads=8, num_kv_heads=8, head_dim=128,
+                                    max_position=4096, num_experts=8, top_k_experts=2),
     "tiny-mixtral-tp": ModelConfig(name="tiny-mixtral-tp", arch="mixtral", vocab_size=1024, hidden_size=512,
                                    intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=2, head_dim=128,
                                    max_position=4096, num_experts=4, top_k_experts=2),

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_custom_all_reduce_ipc(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

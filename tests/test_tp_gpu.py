@@ -37,6 +37,19 @@ def test_tp2_matches_tp1_on_gpu(model, ep):
     assert all(a[:2] == b[:2] for a, b in zip(one["greedy"], two["greedy"])) and agree >= 0.8, (one, two)
 
 
+@pytest.mark.parametrize("model,ep", [("tiny-llama-tp8", 1), ("tiny-mixtral-tp8", 8)])
+def test_tp8_matches_tp1_on_gpu(model, ep):
+    """The degree BASELINE configs 4 and 5 run at: 8 ranks (sharing the device on a one-GPU box), the 8-peer custom
+    all-reduce / all-gather / broadcast kernels inside the decode hipGraphs, one expert per rank."""
+    rng = np.random.default_rng(2)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (40, 300, 7)]
+    one = run(model, 1, 1, prompts)
+    eight = run(model, 8, ep, prompts)
+    assert eight["graph_steps"] > 0 and eight["custom_ar"]
+    agree = np.mean([np.mean(np.array(a) == np.array(b)) for a, b in zip(one["greedy"], eight["greedy"])])
+    assert all(a[:2] == b[:2] for a, b in zip(one["greedy"], eight["greedy"])) and agree >= 0.8, (one, eight)
+
+
 @pytest.mark.parametrize("model,ep", [("llama3-8b", 1), ("mixtral-8x7b", 2), ("mixtral-8x7b", 1)])
 def test_tp2_real_shapes_logits_track_tp1(model, ep, tmp_path):
     """Full-width layers (H 4096, 32/8 heads, FFN 14336, 8 experts, real vocabularies), 4 of them to keep it
