@@ -281,20 +281,60 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
 }
 
 // ==================================================================================================
-// Prefill: grid (num_tiles, Hkv), 4 waves.  A tile is TQ = 16·(8/G) consecutive query tokens of one
-// sequence; its 8 column groups (head, 16-token sub-tile) are spread two per wave.  All K/V — paged
+// Prefill: grid (num_tiles, Hkv), 4 waves.  A tile is TQ = 16·(8/G) consecutive query tokens of one sequence; its
+// 8 column groups (head, 16-token sub-tile) are spread two per wave = 32 query columns per wave.  All K/V — paged
 // prefix and the chunk itself — come from the cache (rope_and_cache has already written the chunk).
 //
-// Unlike decode, all four waves of a tile walk the SAME pages, so the K and V pages are staged through
-// LDS: the block copies each 32-token page (K + V, 16 KB bf16 / 8 KB fp8) once, 16 bytes per lane,
-// into a ring of three LDS buffers by LDS-DMA, two pages ahead of the math (one barrier per page, counted
-// vmcnt), and every wave reads its fragments with ds_read_b128.  That cuts the vector-memory traffic of the tile 4× (it was the limiter: 64 KB through
-// the texture path per page against 512 MFMA cycles).  The page keeps its global layout in LDS except
-// that the four 16-byte slots of every 64-byte row are permuted by the row (slot ^ h[(row >> 2) & 3],
-// h = {0,2,3,1}): the 16 lanes the hardware serves together for a ds_read_b128 — {0–3, 12–15, 20–27}
-// etc. — then touch 16 different slots of the 256-byte bank row instead of 8.
+// Staging.  Unlike decode, all four waves of a tile walk the SAME pages, so K and V pages go through LDS: the block
+// copies each 32-token page (K + V, 16 KB bf16 / 8 KB fp8) once by LDS-DMA (global_load_lds, 16 bytes per lane, no
+// VGPRs) into a ring of three stages, two pages ahead of the math (one barrier per page, counted vmcnt), and every
+// wave reads its fragments with ds_read_b128.  The page keeps its global layout in LDS except that the four 16-byte
+// slots of every 64-byte row are permuted by the row (slot ^ h[(row >> 2) & 3], h = {0,2,3,1}; the DMA's LDS image is
+// lane-linear, so the permutation sits on the SOURCE address): the 16 lanes the hardware serves together for a
+// ds_read_b128 — {0–3, 12–15, 20–27} etc. — then touch 16 different slots of the 256-byte bank row.
+//
+// Math on v_mfma_f32_32x32x16_bf16: a wave's 32 query columns are ONE MFMA column set.  Lane (c = lane & 31,
+// hi = lane >> 5) owns column c:
+//   Sᵀ(32 tok × 32 col)  = 8 MFMAs over d (k-step j: d = 16 j + 8 hi …); the lane's 16 accumulators are tokens
+//                          (r & 3) + 8 (r >> 2) + 4 hi of the page;
+//   P fragments          : accumulators 8 jj … 8 jj + 7 are — after exp2 and a bf16 pack — the B fragment of k-step jj
+//                          of P·V, because slots 8 hi + 4 jj … and 16 + 8 hi + 4 jj … of a V page row hold exactly
+//                          those tokens (v_slot, ops/kv_layout.py — the layout serves both MFMA shapes): one
+//                          ds_read_b128 of slot hi and one of slot 2 + hi give the A fragments of both k-steps;
+//   Oᵀ(128 d × 32 col)   = 4 d-tiles × 2 k-steps = 8 MFMAs.
+// Round 1 used the 16×16×32 shape here as decode does (two 16-column sets per wave): 32 MFMA instructions per page
+// instead of 16, two online-softmax states and four row-swap reductions per lane instead of one and one.  Where the
+// time goes (ablations, L = 4096: docs/KERNELS.md): softmax VALU 36 %, issuing the 4 LDS-DMA instructions per wave
+// and page 24 % (≈ 115 cycles each), P·V 23 %; the per-page barrier is free.
 // ==================================================================================================
 __device__ __forceinline__ int slot_swizzle(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+template <bool MASK>
+__device__ __forceinline__ void softmax32(f32x16& s, int tok0, int limit, float scale_log2, float& m, float& lsum,
+                                          float& alpha, bf16x8 (&pb)[2]) {
+  float raw = NEG_BIG;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = s[r];
+    if (MASK) v = (tok0 + (r & 3) + 8 * (r >> 2) <= limit) ? v : NEG_BIG;
+    s[r] = v;
+    raw = fmaxf(raw, v);
+  }
+  float mx = fmaxf(m, raw * scale_log2);
+  auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+  mx = fmaxf(mx, fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])));
+  alpha = fast_exp2(m - mx);
+  m = mx;
+  float ps = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float p = fast_exp2(__builtin_fmaf(s[r], scale_log2, -mx));
+    if (MASK) p = (tok0 + (r & 3) + 8 * (r >> 2) <= limit) ? p : 0.f;
+    ps += p;
+    pb[r >> 3][r & 7] = (short)f2bf(p);
+  }
+  lsum = lsum * alpha + ps;
+}
 
 template <bool KV8>
 __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
@@ -308,17 +348,16 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
     v_scale = kv_scales[Hkv + blockIdx.y];
   }
   constexpr int ESZ = KV8 ? 1 : 2;
-  constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;            // one K (or V) page of one kv head
-  constexpr int NCH = PAGE_BYTES / (16 * 256);            // 16-byte chunks per thread and operand: 2 (bf16) / 1 (fp8)
-  constexpr int NSTAGE = 3;                               // LDS ring: page b is read while b+1 and b+2 are in flight
-  constexpr int NDMA = 2 * NCH;                           // LDS-DMA instructions per thread and page
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * PAGE_BYTES];   // [stage][K | V]
+  constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;
+  constexpr int NCH = PAGE_BYTES / (16 * 256);
+  constexpr int NSTAGE = 3;
+  constexpr int NDMA = 2 * NCH;
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * PAGE_BYTES];
 
   const int kvh = blockIdx.y;
-  const int G = Hq / Hkv;                      // 1, 2, 4 or 8 (checked on the host)
+  const int G = Hq / Hkv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 15, g = lane >> 4;
-  // work list in reverse: within a sequence the later tiles see more context (causal), so the long ones start first
+  const int c32 = lane & 31, hi = lane >> 5;
   const int tile_id = gridDim.x - 1 - blockIdx.x;
   const int seq = tile_seq[tile_id], q0 = tile_q0[tile_id];
   const int qs = query_start_loc[seq];
@@ -326,56 +365,50 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   const int L = seq_lens[seq];
   const int ctx = L - n_new;
 
-  int head[2], qtok[2], qpos[2];
-  bool valid[2];
+  // this lane's column: column group cg = 2·wave + (c32 >> 4) is (head cg % G, 16-token sub-tile cg / G)
+  const int cg = 2 * wave + (c32 >> 4);
+  const int head = cg % G;
+  const int qtok = q0 + (cg / G) * 16 + (c32 & 15);
+  const bool valid = qtok < n_new;
+  const int qpos = ctx + min(qtok, n_new - 1);
   int first_tok = 1 << 30, last_pos = -1;      // wave-uniform bounds over both column groups
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int cg = 2 * wave + i;
-    head[i] = cg % G;
-    const int t0 = q0 + (cg / G) * 16;
-    qtok[i] = t0 + col;
-    valid[i] = qtok[i] < n_new;
-    qpos[i] = ctx + min(qtok[i], n_new - 1);
+    const int t0 = q0 + ((2 * wave + i) / G) * 16;
     if (t0 < n_new) {
       first_tok = min(first_tok, ctx + t0);
       last_pos = max(last_pos, ctx + min(t0 + 15, n_new - 1));
     }
   }
-  // Every wave takes part in staging all pages of the tile; the math stops at the wave's own causal horizon
-  // (waves whose sub-tiles lie past the end of the chunk do no math at all).
   const int my_nblk = last_pos < 0 ? 0 : (last_pos >> 5) + 1;
   const int tile_tokens = 16 * (8 / G);
   const int nblk = ((ctx + min(q0 + tile_tokens, n_new) - 1) >> 5) + 1;
 
-  bf16x8 qf[2][4];
+  // Qᵀ fragments: k-step j covers d = 16 j + 8 hi … + 7 (fp8 pages keep d in 64-wide chunks: same d, other address)
+  bf16x8 qf[8];
+  {
+    const uint16_t* qp = q + (int64_t)(qs + min(qtok, n_new - 1)) * q_stride + (kvh * G + head) * HD + 8 * hi;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const uint16_t* qp = q + (int64_t)(qs + min(qtok[i], n_new - 1)) * q_stride + (kvh * G + head[i]) * HD;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) qf[i][c] = *reinterpret_cast<const bf16x8*>(qp + KLoader<KV8>::q_d0(c, g));
+    for (int j = 0; j < 8; ++j) qf[j] = *reinterpret_cast<const bf16x8*>(qp + 16 * j);
   }
 
-  f32x4 o[2][8];
+  f32x16 o[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int n = 0; n < 8; ++n) o[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m[2] = {NEG_BIG, NEG_BIG}, lsum[2] = {0.f, 0.f};
+    for (int r = 0; r < 16; ++r) o[n][r] = 0.f;
+  float m = NEG_BIG, lsum = 0.f;
 
   const int* bt = block_tables + (int64_t)seq * max_blocks;
   const char* kc = reinterpret_cast<const char*>(k_cache);
   const char* vc = reinterpret_cast<const char*>(v_cache);
 
-  // ---- staging: LDS-DMA (global_load_lds, 16 bytes per lane, no VGPRs).  One wave instruction fills 1 KB of LDS in
-  // lane order, so the slot permutation is applied on the SOURCE side: LDS chunk ci = (row, physical slot) receives
-  // global chunk (row, slot ^ h(row)).  Thread owns LDS chunks ci = tid + 256 i of the K page and of the V page.
   int src_k[NCH], src_v[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int ci = tid + 256 * i, row = ci >> 2, slot = ci & 3;
-    src_k[i] = (row * 4 + (slot ^ slot_swizzle(row))) * 16;                // 64-byte rows in both dtypes
-    src_v[i] = KV8 ? ci * 16 : src_k[i];                                   // fp8 V: 32-byte rows, 8-byte reads, linear
+    src_k[i] = (row * 4 + (slot ^ slot_swizzle(row))) * 16;
+    src_v[i] = KV8 ? ci * 16 : src_k[i];
   }
   using gptr_t = const __attribute__((address_space(1))) void*;
   using lptr_t = __attribute__((address_space(3))) void*;
@@ -383,16 +416,23 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   {                                                                                                                \
     const int64_t page_ = ((int64_t)bt[b_] * Hkv + kvh) * PAGE_BYTES;                                             \
     _Pragma("unroll") for (int i = 0; i < NCH; ++i) {                                                              \
-      char* dst_ = smem + (buf_) * 2 * PAGE_BYTES + (wave + 4 * i) * 1024;       /* wave-uniform; + lane·16 by hardware */ \
+      char* dst_ = smem + (buf_) * 2 * PAGE_BYTES + (wave + 4 * i) * 1024;                                         \
       __builtin_amdgcn_global_load_lds((gptr_t)(kc + page_ + src_k[i]), (lptr_t)dst_, 16, 0, 0);                   \
       __builtin_amdgcn_global_load_lds((gptr_t)(vc + page_ + src_v[i]), (lptr_t)(dst_ + PAGE_BYTES), 16, 0, 0);    \
     }                                                                                                              \
   }
-  const int lane_off = col * 64 + ((g ^ slot_swizzle(col)) << 4);           // this lane's 16 bytes of a 16-row group
+  // Lane offsets inside a staged page.  Rows of 64 bytes (K: token rows of a d chunk; bf16 V: d rows) carry the slot
+  // swizzle of their row; it depends on (row >> 2) & 3 only, and every row this lane reads is c32 + a multiple of 32.
+  const int swz = slot_swizzle(c32);
+  int k_off[2];                                   // bf16: logical slot 2 (j & 1) + hi;  fp8: slot j & 3, byte 8 hi inside
+#pragma unroll
+  for (int p = 0; p < 2; ++p) k_off[p] = c32 * 64 + (((2 * p + hi) ^ swz) << 4);
+  int k8_off[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) k8_off[p] = c32 * 64 + ((p ^ swz) << 4) + 8 * hi;
+  const int v_off0 = c32 * 64 + ((hi ^ swz) << 4), v_off1 = c32 * 64 + (((2 + hi) ^ swz) << 4);
+  const int v8_off = c32 * 32 + 8 * hi;
 
-  // Prefetch distance two pages: one page of math (≈ 1 k cycles) is shorter than an HBM round trip under load, so
-  // with a single page in flight every iteration ended in a full drain.  vmcnt is counted: "≤ NDMA outstanding" means
-  // everything but the newest page has landed; the drain only happens on the last page.
   DLI_STAGE(0, 0);
   if (nblk > 1) {
     DLI_STAGE(1, 1);
@@ -401,90 +441,80 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  int st = 0;                                             // stage of page b
+  int st = 0;
   for (int b = 0; b < nblk; ++b) {
-    // page b+2 → the stage read during page b-1 (every wave is past that barrier)
     const bool ahead = b + 2 < nblk;
-    const int st2 = st == 0 ? NSTAGE - 1 : st - 1;        // (b + 2) % 3 == (b - 1) % 3
+    const int st2 = st == 0 ? NSTAGE - 1 : st - 1;
     if (ahead) DLI_STAGE(b + 2, st2);
     if (b < my_nblk) {
       const char* kb = smem + st * 2 * PAGE_BYTES;
       const char* vb = kb + PAGE_BYTES;
-      const bool need_mask = b * 32 + 31 > first_tok;   // some query of this wave sits before the page end
-      f32x4 s[2][2];
+      f32x16 s;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        bf16x8 kf[4];
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16x8 kf;
         if constexpr (!KV8) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) kf[c] = *reinterpret_cast<const bf16x8*>(kb + (c * 32 + rt * 16) * 64 + lane_off);
+          kf = *reinterpret_cast<const bf16x8*>(kb + (j >> 1) * 2048 + k_off[j & 1]);
         } else {
-#pragma unroll
-          for (int c2 = 0; c2 < 2; ++c2) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(kb + (c2 * 32 + rt * 16) * 64 + lane_off);
-            fp8x4_to_bf16(raw.x, kf[2 * c2], 0);
-            fp8x4_to_bf16(raw.y, kf[2 * c2], 4);
-            fp8x4_to_bf16(raw.z, kf[2 * c2 + 1], 0);
-            fp8x4_to_bf16(raw.w, kf[2 * c2 + 1], 4);
-          }
+          const uint2 raw = *reinterpret_cast<const uint2*>(kb + (j >> 2) * 2048 + k8_off[j & 3]);
+          fp8x4_to_bf16(raw.x, kf, 0);
+          fp8x4_to_bf16(raw.y, kf, 4);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          s[i][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) s[i][rt] = mfma16(kf[c], qf[i][c], s[i][rt]);
-        }
+        s = mfma32(kf, qf[j], s);
       }
       bf16x8 pb[2];
-      float alpha[2];
-      const int tok0 = b * 32 + 4 * g;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (need_mask) pb[i] = softmax_step<true>(s[i], tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
-        else pb[i] = softmax_step<false>(s[i], tok0, qpos[i], scale_log2, m[i], lsum[i], alpha[i]);
-      }
-      // the running maximum settles after the first pages: skip the 64 accumulator multiplies when no lane moved
-      // (a real branch — the empty asm keeps the compiler from turning it into 64 selects)
-      if (__any(alpha[0] != 1.f || alpha[1] != 1.f)) {
+      float alpha;
+      const int tok0 = b * 32 + 4 * hi;
+      if (b * 32 + 31 > first_tok) softmax32<true>(s, tok0, qpos, scale_log2, m, lsum, alpha, pb);
+      else softmax32<false>(s, tok0, qpos, scale_log2, m, lsum, alpha, pb);
+      if (__any(alpha != 1.f)) {
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int n = 0; n < 8; ++n) o[i][n] *= alpha[i];
+        for (int n = 0; n < 4; ++n) o[n] *= alpha;
       }
 #pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        bf16x8 vf;
+      for (int n = 0; n < 4; ++n) {
+        bf16x8 v0, v1;                           // slots hi and 2 + hi of row d = 32 n + c32: [k-step 0 | k-step 1] halves
         if constexpr (!KV8) {
-          vf = *reinterpret_cast<const bf16x8*>(vb + (16 * n) * 64 + lane_off);
+          v0 = *reinterpret_cast<const bf16x8*>(vb + n * 2048 + v_off0);
+          v1 = *reinterpret_cast<const bf16x8*>(vb + n * 2048 + v_off1);
         } else {
-          const uint2 raw = *reinterpret_cast<const uint2*>(vb + (16 * n + col) * 32 + 8 * g);
-          fp8x4_to_bf16(raw.x, vf, 0);
-          fp8x4_to_bf16(raw.y, vf, 4);
+          const uint2 r0 = *reinterpret_cast<const uint2*>(vb + n * 1024 + v8_off);
+          const uint2 r1 = *reinterpret_cast<const uint2*>(vb + n * 1024 + v8_off + 16);
+          fp8x4_to_bf16(r0.x, v0, 0);
+          fp8x4_to_bf16(r0.y, v0, 4);
+          fp8x4_to_bf16(r1.x, v1, 0);
+          fp8x4_to_bf16(r1.y, v1, 4);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) o[i][n] = mfma16(vf, pb[i], o[i][n]);
+        const bf16x8 a0 = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        const bf16x8 a1 = {v0[4], v0[5], v0[6], v0[7], v1[4], v1[5], v1[6], v1[7]};
+        o[n] = mfma32(a0, pb[0], o[n]);
+        o[n] = mfma32(a1, pb[1], o[n]);
       }
     }
-    // my share of page b+1 has landed in LDS (page b+2 may still be in flight)
     if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     st = st == NSTAGE - 1 ? 0 : st + 1;
   }
 
+  {
+    auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+    const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if (valid) {
+      const float rcp = l > 0.f ? v_scale / l : 0.f;
+      uint16_t* op = out + (int64_t)(qs + qtok) * out_stride + (kvh * G + head) * HD + 4 * hi;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float l = group_sum(lsum[i]);
-    if (!valid[i]) continue;
-    const float r = l > 0.f ? v_scale / l : 0.f;
-    uint16_t* op = out + (int64_t)(qs + qtok[i]) * out_stride + (kvh * G + head[i]) * HD + 4 * g;
+      for (int n = 0; n < 4; ++n)
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      bf16x4 w;
+        for (int r4 = 0; r4 < 4; ++r4) {
+          bf16x4 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (short)f2bf(o[i][n][e] * r);
-      *reinterpret_cast<bf16x4*>(op + 16 * n) = w;
+          for (int e = 0; e < 4; ++e) w[e] = (short)f2bf(o[n][4 * r4 + e] * rcp);
+          *reinterpret_cast<bf16x4*>(op + 32 * n + 8 * r4) = w;
+        }
     }
   }
 #undef DLI_STAGE

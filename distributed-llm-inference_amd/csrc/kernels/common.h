@@ -22,6 +22,15 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
                                                  c, 0, 0, 0);
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator fragment
+
+// D(32x32) += A(32x16) * B(16x32).  Lane l (c = l & 31, hi = l >> 5) holds A[row c][k 8hi+j], B[k 8hi+j][col c],
+// D[row (r & 3) + 8 (r >> 2) + 4 hi][col c] for r = 0..15.
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_mfma, a), __builtin_bit_cast(bf16x8_mfma, b),
+                                                 c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float bf2f(uint16_t u) { return __uint_as_float(static_cast<uint32_t>(u) << 16); }
 
 // round-to-nearest-even via the native conversion (v_cvt_pk_bf16_f32 on gfx950; keeps NaN a NaN)
