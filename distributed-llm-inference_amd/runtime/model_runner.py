@@ -13,6 +13,7 @@ dimension, hence fixed per bucket at capture time (small buckets → more splits
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Optional
 
@@ -33,6 +34,9 @@ _DUMP_LOGITS = __import__("os").environ.get("DLI_DUMP_LOGITS", "")
 def _pinned(shape, dtype, pin):
     t = torch.zeros(shape, dtype=dtype)
     return t.pin_memory() if pin else t
+
+
+_DEBUG_BOUNDS = os.environ.get("DLI_DEBUG_BOUNDS") == "1"
 
 
 class ModelRunner:
@@ -325,6 +329,8 @@ class ModelRunner:
             self._pad_decode(B, bucket)
         if not tp_staged:
             self._copy_in()
+        if _DEBUG_BOUNDS:
+            self._check_bounds(B if not bucket else bucket, T if not bucket else bucket, n_cow)
         if n_cow:
             # n > 1 forks: give the children private copies of the page they are about to write (every layer's K and V;
             # stream-ordered behind the step that filled the source pages, ahead of this step's kernels)
@@ -356,6 +362,26 @@ class ModelRunner:
         self._forward_sample(T, S, meta)
         self.stats["eager_steps"] += 1
         return self._fetch(S)
+
+    def _check_bounds(self, B: int, T: int, n_cow: int) -> None:
+        """``DLI_DEBUG_BOUNDS=1``: before any kernel of the step runs, read the step's metadata back
+        from the DEVICE buffer — what this rank's kernels will really see, on TP workers too — and check every index
+        against this rank's cache: the kernels themselves do no bounds checks.  Synchronises; debug only."""
+        dv, nb = self.dv, self.num_blocks
+        slot = dv["slot"][:T].cpu().numpy()
+        seq_lens = dv["seq_lens"][:B].cpu().numpy()
+        bt = dv["bt"][:B].cpu().numpy()
+        ids = dv["input"][:T].cpu().numpy()
+        assert slot.size == 0 or (slot.max() < nb * KV_BLOCK_SIZE and slot.min() >= -1), \
+            f"slot out of range: [{slot.min()}, {slot.max()}] with {nb} blocks"
+        for i in range(B):
+            used = (int(seq_lens[i]) + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+            row = bt[i, :used]
+            assert row.size == 0 or (row.min() >= 0 and row.max() < nb), f"block table row {i}: {row.min()}..{row.max()} / {nb}"
+        assert ids.size == 0 or ids.max() < self.cfg.model.vocab_size, f"token id {ids.max()} >= vocab"
+        if n_cow:
+            cow = dv["cow"][:2 * n_cow].cpu().numpy()
+            assert cow.min() >= -1 and cow.max() < nb, f"copy-on-write page out of range: {cow}"
 
     def _fetch(self, S):
         """Queue the D2H copy of the sampled ids; the handle is resolved by ``collect``."""

@@ -431,3 +431,19 @@ def test_fp8_kv_scale_calibration_matters_when_kv_values_are_small():
     st = eng.runner.selftest["fp8_kv_scales"]
     assert 0 < st["k_scale_max"] < 0.05 and 0 < st["v_scale_max"] < 0.05          # far below the unit scale
     assert agree(exact, cal) >= 0.8 and agree(exact, cal) > agree(exact, unit) + 0.3
+
+
+def test_debug_bounds_check_passes_on_good_steps_and_catches_a_short_cache(monkeypatch):
+    """DLI_DEBUG_BOUNDS=1: every step's slots / block tables / token ids are checked against THIS rank's
+    cache before a kernel sees them — the failure mode of a TP worker with fewer KV blocks than the driver."""
+    from dli_amd.runtime import model_runner
+    monkeypatch.setattr(model_runner, "_DEBUG_BOUNDS", True)
+    eng = make_engine("tiny-llama")
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(3, 500, size=n).tolist() for n in (40, 90, 7)]
+    assert eng.generate(None, GREEDY, prompt_ids=prompts) == [dense_greedy(eng, p, 12) for p in prompts]
+    eng.runner.num_blocks = 1                              # pretend this rank's cache is smaller than the block manager's
+    eng.add_request("x", prompt_ids=prompts[1], params=GREEDY)
+    with pytest.raises(AssertionError, match="out of range|block table"):
+        while eng.has_unfinished():
+            eng.step()
