@@ -2,7 +2,8 @@
 //
 // One 256-thread workgroup per 4 consecutive tokens.  Work items are 8-element (16-byte) chunks: a q/k item owns
 // the pair (x[d0:d0+8], x[d0+64:d0+72]) of one head, so both halves of the rotation are produced by
-// the same thread; cos/sin come from a host-built fp32 table (no device trig).  Rotated k goes back
+// the same thread; cos/sin come from a host-built fp32 table (no device trig), loaded once per (token, chunk) and
+// reused over the heads a thread walks.  Rotated k goes back
 // into the qkv buffer (the prefill kernel reads everything from the cache, but the in-place result
 // keeps the op's semantics testable) and into the K page as one 16-byte store per chunk; v goes into
 // the transposed, slot-permuted V page (layout: ops/kv_layout.py).
@@ -28,58 +29,73 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(uint16_t* __restrict__ 
                                                          void* __restrict__ k_cache_, void* __restrict__ v_cache_,
                                                          int T, int Hq, int Hkv, float k_inv_scale_, float v_inv_scale_,
                                                          const float* __restrict__ kv_scales) {   // [k | v][Hkv] or null
-  const int t0 = blockIdx.x * TB;
+  // Workgroup → token group.  Hardware deals workgroups round-robin over the 8 XCDs, each with its own L2, and a
+  // 64-byte V page row is completed by 8 consecutive 4-token groups (8 bytes each): with group = blockIdx those eight
+  // partial writes sit in eight different L2s and leave as partial lines.  XCD x takes the x-th eighth of the groups
+  // instead, so neighbours in the batch are neighbours in one L2 and merge there.
+  const int per_xcd = (gridDim.x + 7) >> 3;
+  const int grp = TB == 1 ? (int)blockIdx.x : (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (grp * TB >= T) return;
+  const int t0 = grp * TB;
   const int nt = min(TB, T - t0);
-  const int n_rot = (Hq + Hkv) * 8;
 
-  // ---- q/k: rotate in place, k also into its K page.  Items of the TB tokens are flattened so that every pass of the
-  // 256 threads is full ((Hq+Hkv)·8 = 320 items per token for Llama-3-8B).
-  for (int it = threadIdx.x; it < n_rot * nt; it += blockDim.x) {
-    const int ti = it / n_rot, r = it - ti * n_rot;
-    const int64_t t = t0 + ti;
-    uint16_t* row = qkv + t * row_stride;
-    const int slot = slot_mapping[t];
-    const int head = r >> 3, j = r & 7;
-    uint16_t* p = row + head * D + j * 8;
-    bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-    bf16x8 b = *reinterpret_cast<const bf16x8*>(p + 64);
-    if (cos_sin != nullptr) {
-      float fa[8], fb[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { fa[e] = bf2f((uint16_t)a[e]); fb[e] = bf2f((uint16_t)b[e]); }
-      const float* cs = cos_sin + (int64_t)positions[t] * D + j * 8;
-      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs), c1 = *reinterpret_cast<const f32x4*>(cs + 4);
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + 64), s1 = *reinterpret_cast<const f32x4*>(cs + 68);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float c = e < 4 ? c0[e] : c1[e - 4], sn = e < 4 ? s0[e] : s1[e - 4];
-        const float x1 = fa[e], x2 = fb[e];
-        a[e] = (short)f2bf(x1 * c - x2 * sn);
-        b[e] = (short)f2bf(x2 * c + x1 * sn);
+  // ---- q/k: rotate in place, k also into its K page.  Thread = (token of the workgroup, chunk j of the half-row,
+  // head group hg); it loads the 16 cos/sin values of (position, j) ONCE and walks heads hg, hg + NG, … with them
+  // (round 1 loaded the table per (head, j) item: 64 bytes of table for 32 bytes of data).  Lanes j = 0..7 of a head
+  // cover 128 contiguous bytes, the 8 head groups of a wave 8 such lines: every load and store is whole cache lines.
+  constexpr int NG = 256 / (TB * 8);                       // head groups: 8 (prefill form), 32 (decode form)
+  {
+    const int ti = threadIdx.x / (8 * NG), rem = threadIdx.x - ti * (8 * NG);
+    const int hg = rem >> 3, j = rem & 7;
+    if (ti < nt) {
+      const int64_t t = t0 + ti;
+      uint16_t* row = qkv + t * row_stride;
+      const int slot = slot_mapping[t];
+      f32x4 c0, c1, s0, s1;
+      if (cos_sin != nullptr) {
+        const float* cs = cos_sin + (int64_t)positions[t] * D + j * 8;
+        c0 = *reinterpret_cast<const f32x4*>(cs);
+        c1 = *reinterpret_cast<const f32x4*>(cs + 4);
+        s0 = *reinterpret_cast<const f32x4*>(cs + 64);
+        s1 = *reinterpret_cast<const f32x4*>(cs + 68);
       }
-      *reinterpret_cast<bf16x8*>(p) = a;
-      *reinterpret_cast<bf16x8*>(p + 64) = b;
-    }
-    if (head >= Hq && slot >= 0) {             // k head → K page
-      const int h = head - Hq, blk = slot >> 5, tok = slot & 31;
-      const int64_t page = (int64_t)blk * Hkv + h;
-      if (!KV8) {
-        uint16_t* kc = reinterpret_cast<uint16_t*>(k_cache_) + page * (D * 32);
-        const int d0 = j * 8, d1 = 64 + j * 8;   // chunk c = d/32, offset d%32
-        *reinterpret_cast<bf16x8*>(kc + ((d0 >> 5) * 32 + tok) * 32 + (d0 & 31)) = a;
-        *reinterpret_cast<bf16x8*>(kc + ((d1 >> 5) * 32 + tok) * 32 + (d1 & 31)) = b;
-      } else {
-        uint8_t* kc = reinterpret_cast<uint8_t*>(k_cache_) + page * (D * 32);
-        const float k_inv_scale = kv_scales != nullptr ? fast_rcp(kv_scales[h]) : k_inv_scale_;
-        uint64_t pa = 0, pb = 0;
+      for (int head = hg; head < Hq + Hkv; head += NG) {
+        uint16_t* p = row + head * D + j * 8;
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(p + 64);
+        if (cos_sin != nullptr) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pa |= (uint64_t)f_to_fp8(bf2f((uint16_t)a[e]) * k_inv_scale) << (8 * e);
-          pb |= (uint64_t)f_to_fp8(bf2f((uint16_t)b[e]) * k_inv_scale) << (8 * e);
+          for (int e = 0; e < 8; ++e) {
+            const float c = e < 4 ? c0[e] : c1[e - 4], sn = e < 4 ? s0[e] : s1[e - 4];
+            const float x1 = bf2f((uint16_t)a[e]), x2 = bf2f((uint16_t)b[e]);
+            a[e] = (short)f2bf(x1 * c - x2 * sn);
+            b[e] = (short)f2bf(x2 * c + x1 * sn);
+          }
+          *reinterpret_cast<bf16x8*>(p) = a;
+          *reinterpret_cast<bf16x8*>(p + 64) = b;
         }
-        // chunk c = d/64: first half is chunk 0, second half chunk 1
-        *reinterpret_cast<uint64_t*>(kc + (0 * 32 + tok) * 64 + j * 8) = pa;
-        *reinterpret_cast<uint64_t*>(kc + (1 * 32 + tok) * 64 + j * 8) = pb;
+        if (head >= Hq && slot >= 0) {             // k head → K page
+          const int h = head - Hq, blk = slot >> 5, tok = slot & 31;
+          const int64_t page = (int64_t)blk * Hkv + h;
+          if (!KV8) {
+            uint16_t* kc = reinterpret_cast<uint16_t*>(k_cache_) + page * (D * 32);
+            const int d0 = j * 8, d1 = 64 + j * 8;   // chunk c = d/32, offset d%32
+            *reinterpret_cast<bf16x8*>(kc + ((d0 >> 5) * 32 + tok) * 32 + (d0 & 31)) = a;
+            *reinterpret_cast<bf16x8*>(kc + ((d1 >> 5) * 32 + tok) * 32 + (d1 & 31)) = b;
+          } else {
+            uint8_t* kc = reinterpret_cast<uint8_t*>(k_cache_) + page * (D * 32);
+            const float k_inv_scale = kv_scales != nullptr ? fast_rcp(kv_scales[h]) : k_inv_scale_;
+            uint64_t pa = 0, pb = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              pa |= (uint64_t)f_to_fp8(bf2f((uint16_t)a[e]) * k_inv_scale) << (8 * e);
+              pb |= (uint64_t)f_to_fp8(bf2f((uint16_t)b[e]) * k_inv_scale) << (8 * e);
+            }
+            // chunk c = d/64: first half is chunk 0, second half chunk 1
+            *reinterpret_cast<uint64_t*>(kc + (0 * 32 + tok) * 64 + j * 8) = pa;
+            *reinterpret_cast<uint64_t*>(kc + (1 * 32 + tok) * 64 + j * 8) = pb;
+          }
+        }
       }
     }
   }
@@ -150,7 +166,7 @@ void launch_rope_and_cache(void* qkv, int64_t row_stride, const int* positions, 
                            bool kv_fp8, float k_scale, float v_scale, const float* kv_scales, hipStream_t stream) {
   if (T == 0) return;
 #define DLI_ROPE(KV8_, TB_, ks_, vs_)                                                                                   \
-  hipLaunchKernelGGL((rope_cache_kernel<KV8_, TB_>), dim3((T + TB_ - 1) / TB_), dim3(256), 0, stream, (uint16_t*)qkv,   \
+  hipLaunchKernelGGL((rope_cache_kernel<KV8_, TB_>), dim3((((T + TB_ - 1) / TB_) + 7) / 8 * 8), dim3(256), 0, stream, (uint16_t*)qkv,   \
                      row_stride, positions, cos_sin, slot_mapping, k_cache, v_cache, T, Hq, Hkv, ks_, vs_, kv_fp8 ? kv_scales : nullptr)
   const bool small = T <= 128;                          // ≤ 128 workgroups either way: take the short dependency chain
   if (kv_fp8) {
