@@ -281,7 +281,7 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
 }
 
 // ==================================================================================================
-// Prefill: grid (num_tiles, Hkv), 4 waves.  A tile is TQ = 16·(8/G) consecutive query tokens of one sequence; its
+// Prefill: one workgroup of 4 waves per (tile, kv head).  A tile is TQ = 16·(8/G) consecutive query tokens of one sequence; its
 // 8 column groups (head, 16-token sub-tile) are spread two per wave = 32 query columns per wave.  All K/V — paged
 // prefix and the chunk itself — come from the cache (rope_and_cache has already written the chunk).
 //
@@ -341,12 +341,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens,
     const int* __restrict__ query_start_loc, const int* __restrict__ tile_seq, const int* __restrict__ tile_q0,
-    uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, float scale_log2, float v_scale,
+    uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, int num_tiles, float scale_log2, float v_scale,
     const float* __restrict__ kv_scales) {
-  if (KV8 && kv_scales != nullptr) {
-    scale_log2 *= kv_scales[blockIdx.y];
-    v_scale = kv_scales[Hkv + blockIdx.y];
-  }
   constexpr int ESZ = KV8 ? 1 : 2;
   constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;
   constexpr int NCH = PAGE_BYTES / (16 * 256);
@@ -354,11 +350,23 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   constexpr int NDMA = 2 * NCH;
   __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * PAGE_BYTES];
 
-  const int kvh = blockIdx.y;
+  // Block → (kv head, tile).  Workgroups are dealt round-robin over the 8 XCDs (private L2s); tiles of one sequence and
+  // kv head read the same K/V pages.  XCD x takes the x-th eighth of the order (kv head, tile): with 8 kv heads every
+  // XCD serves ONE head — a sequence's pages of that head are fetched into one L2 instead of eight — and with fewer
+  // heads (TP shards) a contiguous range of tiles.
+  const int total = num_tiles * Hkv;
+  const int per_xcd = (total + 7) >> 3;
+  const int lin = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || lin >= total) return;
+  const int kvh = lin / num_tiles;
   const int G = Hq / Hkv;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c32 = lane & 31, hi = lane >> 5;
-  const int tile_id = gridDim.x - 1 - blockIdx.x;
+  const int tile_id = num_tiles - 1 - (lin - kvh * num_tiles);
+  if (KV8 && kv_scales != nullptr) {
+    scale_log2 *= kv_scales[kvh];
+    v_scale = kv_scales[Hkv + kvh];
+  }
   const int seq = tile_seq[tile_id], q0 = tile_q0[tile_id];
   const int qs = query_start_loc[seq];
   const int n_new = query_start_loc[seq + 1] - qs;
@@ -552,15 +560,15 @@ void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, 
   if (num_tiles == 0) return;
   if (kv_scales != nullptr) k_scale = v_scale = 1.f;
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
-  dim3 grid(num_tiles, Hkv);
+  dim3 grid((num_tiles * Hkv + 7) / 8 * 8);
   if (kv_fp8)
     hipLaunchKernelGGL(paged_prefill_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
-                       out_stride, Hq, Hkv, scale_log2, v_scale, kv_scales);
+                       out_stride, Hq, Hkv, num_tiles, scale_log2, v_scale, kv_scales);
   else
     hipLaunchKernelGGL(paged_prefill_kernel<false>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
-                       out_stride, Hq, Hkv, scale_log2, 1.f, nullptr);
+                       out_stride, Hq, Hkv, num_tiles, scale_log2, 1.f, nullptr);
 }
 
 }  // namespace dli
