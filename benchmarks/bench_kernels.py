@@ -312,7 +312,8 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     ops.hip()
-    run = lambda name: not a.only or a.only in name
+    only = [t for t in a.only.split(",") if t]
+    run = lambda name: not only or any(t in name for t in only)
     if run("norm"):
         for T in (256, 4096):
             bench_norm(T)
