@@ -123,7 +123,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* 
                                                                       int M, int N, int K) {
   extern __shared__ __attribute__((aligned(1024))) char sk_smem[];
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * (SWIGLU ? 8 : 16);
+  // XCD x streams the x-th eighth of the weight rows: neighbouring 16-column pieces of an output row (32 bytes each)
+  // are then written through ONE L2 and leave as whole lines
+  const int per_xcd = (gridDim.x + 7) >> 3;
+  const int wg = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (wg * 16 >= N) return;
+  const int n0 = wg * (SWIGLU ? 8 : 16);
   // DMA sources: instruction i of a tile covers tile rows 4i + (lane>>4); this lane supplies LDS chunk p = lane&15,
   // i.e. global chunk p ^ row.  Rows ≥ M repeat the last token.
   const char* wsrc[4];
@@ -222,7 +227,7 @@ template <int XI, bool SWIGLU, int NW>
 static void launch_skinny(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, hipStream_t stream) {
   constexpr int lds = NW * 2 * (XI * 1024 + SK_TILE);
-  hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU, NW>), dim3(N / 16), dim3(NW * 64), lds, stream, (const uint16_t*)x,
+  hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU, NW>), dim3((N / 16 + 7) / 8 * 8), dim3(NW * 64), lds, stream, (const uint16_t*)x,
                      x_stride, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, out_stride, M, N, K);
 }
 
