@@ -304,8 +304,8 @@ __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restr
 //   Oᵀ(128 d × 32 col)   = 4 d-tiles × 2 k-steps = 8 MFMAs.
 // Round 1 used the 16×16×32 shape here as decode does (two 16-column sets per wave): 32 MFMA instructions per page
 // instead of 16, two online-softmax states and four row-swap reductions per lane instead of one and one.  Where the
-// time goes (ablations, L = 4096: docs/KERNELS.md): softmax VALU 36 %, issuing the 4 LDS-DMA instructions per wave
-// and page 24 % (≈ 115 cycles each), P·V 23 %; the per-page barrier is free.
+// time went BEFORE the XCD-aware block mapping below (ablations, L = 4096: docs/KERNELS.md): softmax VALU 36 %,
+// issuing — and waiting on — the 4 LDS-DMA instructions per wave and page 24 %, P·V 23 %; the per-page barrier is free.
 // ==================================================================================================
 __device__ __forceinline__ int slot_swizzle(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
