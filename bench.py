@@ -201,6 +201,11 @@ def main():
     import torch.distributed as dist
 
     layout = launch.Layout.from_env(args.gpus, args.tp, args.ep)
+    # stdout carries exactly ONE line: the JSON of rank 0.  Libraries write there too (gloo prints its connection
+    # messages to stdout from C++), so the real stdout is kept aside and file descriptor 1 joins stderr for the run.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if os.environ.get("DLI_DUMP_STACKS_AFTER"):              # debug aid: where is a hung rank waiting?
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["DLI_DUMP_STACKS_AFTER"]), repeat=True)
@@ -289,7 +294,7 @@ def main():
         })
         if args.num_layers:
             line["INVALID_reduced_model"] = f"--num-layers {args.num_layers}: rehearsal, not the named architecture"
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=result_out, flush=True)
     launch.shutdown(job)
 
 

@@ -26,6 +26,7 @@ def test_self_launch_dp2():
     p, lines = run_bench(["--gpus", "2", "--model", "tiny-llama"])
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, "nothing but that line on stdout (library chatter goes to stderr)"
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["self_launched"] is True
     assert d["vs_baseline"] is None and d["window_too_short"] is True and "value_sustained" in d
