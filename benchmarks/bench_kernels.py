@@ -255,7 +255,9 @@ def bench_gemm256(quick):
                    library_TFLOPs=round(fl / t_gemm / 1e12, 1), speedup_vs_library_path=round(t_lib / t_new, 3))
         del ws
     H, I, E = 4096, 14336, 8
-    for T, El in ([(4096, 8)] if quick else [] if only_shapes else [(1024, 8), (2048, 8), (4096, 8), (8192, 8), (4096, 1)]):
+    moe_ts = os.environ.get("DLI_BENCH_MOE_TS")              # e.g. "384,512,768": sweep the tile-size crossover
+    cases = [(int(v), 8) for v in moe_ts.split(",")] if moe_ts else [(1024, 8), (2048, 8), (4096, 8), (8192, 8), (4096, 1)]
+    for T, El in ([(4096, 8)] if quick else cases if (moe_ts or not only_shapes) else []):
         x = torch.randn(T, H, device=DEV).bfloat16()
         logits = torch.randn(T, E, device=DEV).bfloat16()
         w13 = (torch.randn(El, 2 * I, H, device=DEV) * 0.02).bfloat16()

@@ -222,9 +222,11 @@ Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu) {
   return out;
 }
 
-// row tile of the grouped GEMM: 256 from this many routed rows per local expert on (DLI_MOE_TILE=128|256 forces one)
+// row tile of the grouped GEMM: 256 from this many routed rows per expert on (DLI_MOE_TILE=128|256 forces one).
+// Measured crossover at Mixtral shapes (profiles/kernels_moe_tile_crossover_r2z.txt): 96 rows per expert → 128-row tiles
+// win by 8 %, from 128 rows per expert on the 256-row tile wins by 1.2–1.37 ×.
 const int64_t g_moe_tile_force = std::getenv("DLI_MOE_TILE") ? std::atoll(std::getenv("DLI_MOE_TILE")) : 0;
-const int64_t g_moe_tile256_min_rows = std::getenv("DLI_MOE_TILE256_MIN_ROWS") ? std::atoll(std::getenv("DLI_MOE_TILE256_MIN_ROWS")) : 384;
+const int64_t g_moe_tile256_min_rows = std::getenv("DLI_MOE_TILE256_MIN_ROWS") ? std::atoll(std::getenv("DLI_MOE_TILE256_MIN_ROWS")) : 128;
 
 const int64_t g_moe_splitk_min_blocks256 = std::getenv("DLI_MOE_SPLITK_MIN_BLOCKS256") ? std::atoll(std::getenv("DLI_MOE_SPLITK_MIN_BLOCKS256")) : 512;
 
@@ -248,7 +250,7 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   auto i32 = x.options().dtype(at::kInt);
   const int64_t n = T * top_k;
   // 256-row tiles when the experts see enough rows to fill them (and the shapes divide): gemm256.hip
-  bool big = n / El >= g_moe_tile256_min_rows;
+  bool big = n / E >= g_moe_tile256_min_rows;               // expected rows per expert (local or not) under uniform routing
   if (g_moe_tile_force) big = g_moe_tile_force == 256;
   if (tile_rows) big = tile_rows == 256;                     // A/B measurements in one process
   big = big && I % 128 == 0 && H % 256 == 0 && n * std::max(H, I) * 2 < (int64_t(1) << 32) && 2 * I * H * 2 < (int64_t(1) << 32);
