@@ -52,7 +52,7 @@ SLOS = {
     "mixtral-8x7b": {"relaxed": (2.0, 0.200), "interactive": (0.5, 0.040)},
 }
 # default offered load per replica (requests/s), close to the measured sustainable rate of one replica
-DEFAULT_QPS = {"llama3-8b": 68.0, "llama3-70b": 6.0, "mixtral-8x7b": 26.0}
+DEFAULT_QPS = {"llama3-8b": 68.0, "llama3-70b": 6.0, "mixtral-8x7b": 40.0}
 
 
 def parse(argv=None):
