@@ -223,6 +223,9 @@ class ModelRunner:
         if _DUMP_LOGITS and self.ctx.is_driver and not torch.cuda.is_current_stream_capturing() and not self._dumped:
             self._dumped = True                              # debug aid: first sampled row of the first eager step
             torch.save(logits[0].float().cpu(), _DUMP_LOGITS)
+        if _DEBUG_BOUNDS and not (self.on_gpu and torch.cuda.is_current_stream_capturing()):
+            # the sampler maps a NaN row to token 0 instead of an out-of-range id; in debug mode the NaN itself is the error
+            assert bool(torch.isfinite(logits[: max(S, 1)].float()).all()), "non-finite logits"
         ops.sample(logits, dv["temp"][:S], dv["top_p"][:S], dv["top_k"][:S], dv["seeds"][:S], dv["steps"][:S],
                    out=self.d_sampled[:S])
         return logits
