@@ -150,7 +150,10 @@ __device__ __forceinline__ bf16x8 softmax_step(f32x4 (&s)[2], int tok0, int limi
 }
 
 // ==================================================================================================
-// Decode: grid (num_seqs, Hkv, num_splits), 4 waves; wave w takes pages w, w+4, … of its split.
+// Decode: grid (Hkv, num_seqs, num_splits), 4 waves; wave w takes pages w, w+4, … of its split.  The kv head is the
+// fastest grid index: the 8 heads of a sequence (contiguous 64 KB per page) are read at the same time by neighbouring
+// workgroups, and a long sequence's work is spread over 8 workgroups that start together instead of 8 that start
+// num_seqs ids apart: +3–4 % on mixed-length batches (profiles/kernels_decode_r2aa.txt).
 // ==================================================================================================
 template <bool KV8>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     int64_t out_stride, float* __restrict__ part_o, float* __restrict__ part_ml, int Hq, int Hkv, int num_splits,
     float scale_log2, float v_scale, const float* __restrict__ kv_scales) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int seq = blockIdx.x, kvh = blockIdx.y, split = blockIdx.z;
+  const int seq = blockIdx.y, kvh = blockIdx.x, split = blockIdx.z;
   if (KV8 && kv_scales != nullptr) {                       // calibrated per-(layer, kv head) fp8 scales: [k | v][Hkv]
     scale_log2 *= kv_scales[kvh];
     v_scale = kv_scales[Hkv + kvh];
@@ -538,7 +541,7 @@ void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, c
   if (kv_scales != nullptr) k_scale = v_scale = 1.f;        // the kernels read the per-head values themselves
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
   const size_t lds = (size_t)(4 * G * (HD + 4) + 8 * G) * sizeof(float);
-  dim3 grid(num_seqs, Hkv, num_splits);
+  dim3 grid(Hkv, num_seqs, num_splits);
   if (kv_fp8)
     hipLaunchKernelGGL(paged_decode_kernel<true>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
