@@ -101,3 +101,22 @@ def test_world_size_8_layouts(extra, par):
     assert len(d["device_ids"]) == 8
     if "ep8" in par:
         assert d["comm_per_step"]["a2a_calls"] > 0      # prefill-sized steps dispatched by all-to-all over 8 ranks
+
+
+def test_layout_rank_grouping(monkeypatch):
+    """Pure rank arithmetic of the launcher: consecutive ranks form a TP group, tp_rank 0 drives it."""
+    from dli_amd.runtime.launch import Layout
+    for rank in range(8):
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "8")
+        monkeypatch.setenv("LOCAL_RANK", str(rank))
+        dp = Layout.from_env(8)
+        assert (dp.dp, dp.replica, dp.tp_rank, dp.is_driver) == (8, rank, 0, True) and dp.driver_ranks == list(range(8))
+        l = Layout.from_env(8, tp=4, ep=4)
+        assert (l.dp, l.replica, l.tp_rank, l.is_driver) == (2, rank // 4, rank % 4, rank % 4 == 0)
+        assert l.groups == [[0, 1, 2, 3], [4, 5, 6, 7]] and l.driver_ranks == [0, 4]
+        t = Layout.from_env(8, tp=8)
+        assert t.dp == 1 and t.groups == [list(range(8))] and t.driver_ranks == [0]
+    for bad in (dict(gpus=4), dict(gpus=8, tp=3), dict(gpus=8, tp=4, ep=2)):
+        with pytest.raises(SystemExit):
+            Layout.from_env(**bad)
