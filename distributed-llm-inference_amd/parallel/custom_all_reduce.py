@@ -215,8 +215,12 @@ class CustomAllReduce:
                 except Exception as e:                       # the sweep must never take the engine down
                     row["library_error"] = f"{type(e).__name__}: {e}"
             rows.append(row)
-        if self.error():
-            raise RuntimeError("custom all-reduce kernel timed out during the launch-shape sweep")
+        # a time-out on ANY rank ends the sweep on EVERY rank at this same point (a rank that raised alone would leave
+        # its peers waiting in the broadcast below, and the group with custom all-reduce on some ranks only)
+        flags = [None] * self.world
+        dist.all_gather_object(flags, bool(self.error()), group=self._cpu_group())
+        if any(flags):
+            raise RuntimeError(f"custom all-reduce kernel timed out during the launch-shape sweep (ranks {[i for i, f in enumerate(flags) if f]})")
         rows = self.ctx.broadcast_object(rows, src=0)        # rank 0's clock decides for everyone
         thr, algos, blocks = [], [], []
         use_max = self.max_bytes

@@ -227,5 +227,11 @@ def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None
                           ep_size=ep_size, ep_a2a_min_tokens=ep_a2a_min_tokens if ep_size > 1 else 0)
     if custom_all_reduce and device is not None and device.type == "cuda":
         from .custom_all_reduce import CustomAllReduce
-        ctx.custom_ar = CustomAllReduce.create(ctx, device)
+        ar = CustomAllReduce.create(ctx, device)
+        # all or nothing: one rank without the fast path while its peers wait in the kernels' flag barriers is a hang
+        if not ctx.all_min_int(1 if ar is not None else 0):
+            if ar is not None:
+                ar.enabled = False
+            ar = None
+        ctx.custom_ar = ar
     return ctx
