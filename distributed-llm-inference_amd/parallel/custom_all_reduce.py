@@ -36,24 +36,42 @@ class CustomAllReduce:
         self.world, self.rank = ctx.tp_size, ctx.tp_rank
         self.tuning: dict = {}
         torch.cuda.set_device(device)
-        own = [lib.ar_alloc(max_bytes, False), lib.ar_alloc(max_bytes, False), lib.ar_alloc(lib.ar_signal_bytes(), True)]
-        self._own = own
-        handles = [lib.ar_ipc_handle(p).tolist() for p in own]
-        gathered = [None] * self.world
         group = self._cpu_group()
-        dist.all_gather_object(gathered, handles, group=group)
+        # Set-up is collective, so a failure on one rank must surface on every rank at the same exchange: each phase
+        # runs under try, the outcome travels with the next all-gather, and all ranks raise together (→ create() returns
+        # None everywhere) instead of one rank leaving while its peers wait for it.
+        own, handles, err = [], None, ""
+        try:
+            own = [lib.ar_alloc(max_bytes, False), lib.ar_alloc(max_bytes, False), lib.ar_alloc(lib.ar_signal_bytes(), True)]
+            handles = [lib.ar_ipc_handle(p).tolist() for p in own]
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        self._own = own
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, handles if not err else {"error": err}, group=group)
+        bad = {r: g["error"] for r, g in enumerate(gathered) if isinstance(g, dict)}
+        if bad:
+            raise RuntimeError(f"buffer allocation / IPC export failed on ranks {bad}")
         tables = [[], [], []]
         self._opened = []
-        for r in range(self.world):
-            for k in range(3):
-                if r == self.rank:
-                    tables[k].append(own[k])
-                else:
-                    p = lib.ar_ipc_open(torch.tensor(gathered[r][k], dtype=torch.uint8))
-                    self._opened.append(p)
-                    tables[k].append(p)
-        t = [torch.tensor(x, dtype=torch.int64) for x in tables]
-        self.state = lib.ar_create(self.rank, self.world, t[0], t[1], t[2], max_bytes)
+        err = ""
+        try:
+            for r in range(self.world):
+                for k in range(3):
+                    if r == self.rank:
+                        tables[k].append(own[k])
+                    else:
+                        p = lib.ar_ipc_open(torch.tensor(gathered[r][k], dtype=torch.uint8))
+                        self._opened.append(p)
+                        tables[k].append(p)
+            t = [torch.tensor(x, dtype=torch.int64) for x in tables]
+            self.state = lib.ar_create(self.rank, self.world, t[0], t[1], t[2], max_bytes)
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+        errs = [None] * self.world
+        dist.all_gather_object(errs, err, group=group)
+        if any(errs):
+            raise RuntimeError(f"mapping the peers' buffers failed on ranks { {r: e for r, e in enumerate(errs) if e} }")
         self.enabled = True
         self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         dist.barrier(group=group)
