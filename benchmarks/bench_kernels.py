@@ -118,10 +118,14 @@ def _decode_case(B, ctx, Hq, Hkv, kv_dtype, splits=None):
     return fn, kv_bytes, splits
 
 
-def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0):
+def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0, order="random"):
     """Serving-shaped batch: log-normal context lengths (the BurstGPT length mix), one decode token each."""
     rng = np.random.default_rng(seed)
     ctx = np.clip(rng.lognormal(np.log(mean_ctx) - 0.32, 0.8, size=B), 8, 2048).astype(np.int64)
+    if order == "longest_first":
+        ctx = np.sort(ctx)[::-1].copy()
+    elif order == "shortest_first":
+        ctx = np.sort(ctx)
     nb = (ctx + 31) // 32
     max_nb = int(nb.max())
     nblocks = int(nb.sum()) + 1
@@ -148,8 +152,10 @@ def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0):
 
 def bench_decode(quick):
     for B in ([1024] if quick else [256, 1024, 1400]):
-        fn, nbytes, splits, mean = _decode_mixed_case(B, 770)
-        report("paged_attention_decode(mixed lengths)", timeit(fn), bytes_=nbytes, B=B, mean_ctx=round(mean), splits=splits)
+        for order in ("random", "longest_first", "shortest_first"):
+            fn, nbytes, splits, mean = _decode_mixed_case(B, 770, order=order)
+            report("paged_attention_decode(mixed lengths)", timeit(fn), bytes_=nbytes, B=B, mean_ctx=round(mean), splits=splits,
+                   row_order=order)
     cases = [(256, 700), (64, 700), (8, 2048), (1, 2048), (512, 1024)]
     if quick:
         cases = cases[:2]

@@ -37,6 +37,8 @@ from ..config import SchedulerConfig
 from .request import Request, RequestStatus, ScheduledBatch
 
 
+_LPT_DECODE = __import__("os").environ.get("DLI_DECODE_ORDER", "longest_first") != "fifo"   # A/B knob
+
 class Scheduler:
     def __init__(self, cfg: SchedulerConfig, block_manager, watermark: float = 0.01):
         self.cfg = cfg
@@ -228,8 +230,14 @@ class Scheduler:
             j = max(range(len(picked)), key=lambda i: picked[i][1])
             if picked[j][1] > cut + 1:                      # stays a multi-token chunk; its pages are already allocated
                 picked[j] = (picked[j][0], picked[j][1] - cut)
-        # decodes (single token) first, stable otherwise
-        picked.sort(key=lambda p: p[1] != 1)
+        # decodes (single token) first, LONGEST CONTEXT FIRST among them: the decode-attention grid is dispatched in row
+        # order, one workgroup per (row, kv head), and its work is the row's context — longest-processing-time-first
+        # keeps the tail of the launch short (+3–15 % kernel bandwidth on the trace's length mix,
+        # profiles/kernels_decode_r2ad.txt).  Prefill chunks keep their order.
+        dec = [p for p in picked if p[1] == 1]
+        if len(dec) > 1 and _LPT_DECODE:
+            dec.sort(key=lambda p: -p[0].num_computed)
+        picked = dec + [p for p in picked if p[1] != 1]
         reqs = [p[0] for p in picked]
         num_new = np.fromiter((p[1] for p in picked), dtype=np.int32, count=len(picked))
         num_decode = int((num_new == 1).sum())
