@@ -447,3 +447,17 @@ def test_debug_bounds_check_passes_on_good_steps_and_catches_a_short_cache(monke
     with pytest.raises(AssertionError, match="out of range|block table"):
         while eng.has_unfinished():
             eng.step()
+
+
+def test_decode_rows_are_ordered_longest_context_first():
+    """The decode-attention grid is dispatched in row order: the scheduler hands it the longest contexts first."""
+    eng = make_engine("tiny-llama")
+    rng = np.random.default_rng(9)
+    for i, n in enumerate((5, 60, 20, 40)):
+        eng.add_request(f"r{i}", prompt_ids=rng.integers(3, 500, size=n).tolist(), params=GREEDY)
+    for _ in range(4):
+        eng.step()
+    b = eng.scheduler.schedule()
+    assert b.num_decode == 4
+    ctx = [r.num_computed for r in b.requests[:b.num_decode]]
+    assert ctx == sorted(ctx, reverse=True) and len(set(ctx)) == 4
