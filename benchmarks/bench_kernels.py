@@ -228,13 +228,15 @@ def bench_gemm256(quick):
     (c) MoE block: 128-row tiles (moe.hip) vs 256-row tiles (gemm256.hip)."""
     import torch.nn.functional as F
     lib = ops.hip()
-    shapes = [("8b_gate_up", 28672, 4096, True), ("70b_tp8_gate_up", 7168, 8192, True), ("8b_qkv", 6144, 4096, False),
+    shapes = [("8b_gate_up", 28672, 4096, True), ("70b_tp8_gate_up", 7168, 8192, True), ("70b_gate_up", 57344, 8192, True), ("8b_qkv", 6144, 4096, False),
               ("8b_o", 4096, 4096, False), ("8b_down", 4096, 14336, False), ("70b_tp8_down", 8192, 3584, False)]
     ms_env = os.environ.get("DLI_BENCH_GEMM_MS")          # e.g. "2304,2816,3328": the step sizes the serving loop produces
     ms = tuple(int(v) for v in ms_env.split(",")) if ms_env else (512, 1024, 2048, 4096, 8192)
     only_shapes = os.environ.get("DLI_BENCH_GEMM_SHAPES")
     if only_shapes:
         shapes = [sh for sh in shapes if sh[0] in only_shapes.split(",")]
+    if not only_shapes:
+        shapes = [sh for sh in shapes if sh[0] != "70b_gate_up"]       # 0.9 GB per copy: on request only
     for name, N, K, swiglu in (shapes[:2] if quick else shapes):
         if not swiglu and N % 256:
             continue
