@@ -72,16 +72,28 @@ def prefill_tile_tokens(num_heads: int, num_kv_heads: int) -> int:
     return 16 * max(8 // g, 1)
 
 
-def build_prefill_tiles(query_lens: np.ndarray, first_seq: int, tile_tokens: int):
-    """Host-side work list of the prefill kernel: (sequence index, first query offset) per tile."""
-    seqs, q0s = [], []
+def build_prefill_tiles(query_lens: np.ndarray, first_seq: int, tile_tokens: int, seq_lens: np.ndarray | None = None):
+    """Host-side work list of the prefill kernel: (sequence index, first query offset) per tile.
+
+    The kernel walks the list from its END (causal tiles late in a chunk see the most context).  With ``seq_lens``
+    (context length including the new tokens, per sequence) the list is sorted by the pages a tile reads, ascending, so
+    that walk is longest-processing-time-first over ALL sequences of the step — a chunk that continues a 1500-token
+    context starts before the tiles of fresh short prompts."""
+    seqs, q0s, work = [], [], []
     for i, n in enumerate(query_lens):
         nt = (int(n) + tile_tokens - 1) // tile_tokens
         seqs.append(np.full(nt, first_seq + i, dtype=np.int32))
-        q0s.append(np.arange(nt, dtype=np.int32) * tile_tokens)
+        q0 = np.arange(nt, dtype=np.int32) * tile_tokens
+        q0s.append(q0)
+        if seq_lens is not None:
+            work.append(int(seq_lens[i]) - int(n) + q0)      # context in front of the tile (+ a constant)
     if not seqs:
         return np.zeros(0, np.int32), np.zeros(0, np.int32)
-    return np.concatenate(seqs), np.concatenate(q0s)
+    ts, t0 = np.concatenate(seqs), np.concatenate(q0s)
+    if seq_lens is not None and len(query_lens) > 1:
+        order = np.argsort(np.concatenate(work), kind="stable")
+        ts, t0 = ts[order], t0[order]
+    return ts, t0
 
 
 def choose_decode_splits(num_seqs: int, num_kv_heads: int, max_seq_len: int, num_cus: int = 256) -> int:

@@ -195,7 +195,7 @@ class ModelRunner:
             nv["steps"][:S] = [r.num_output for r in sel]
         n_tiles = 0
         if B > nd:
-            ts, t0 = ops.build_prefill_tiles(batch.num_new[nd:], nd, self.tile_tokens)
+            ts, t0 = ops.build_prefill_tiles(batch.num_new[nd:], nd, self.tile_tokens, self.n_seq_lens[nd:B])
             n_tiles = len(ts)
             nv["tile_seq"][:n_tiles] = ts
             nv["tile_q0"][:n_tiles] = t0
