@@ -197,8 +197,13 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   const char* kc = reinterpret_cast<const char*>(k_cache);
   const char* vc = reinterpret_cast<const char*>(v_cache);
 
+  // the block-table entry of the NEXT page of this wave is fetched one iteration ahead: the entry → page address → 16
+  // fragment loads chain is otherwise paid in full at the top of every iteration
+  int blk_next = b_begin + wave < b_end ? bt[b_begin + wave] : 0;
   for (int b = b_begin + wave; b < b_end; b += 4) {
-    const int64_t page = ((int64_t)bt[b] * Hkv + kvh) * (PAGE_ELEMS * ESZ);
+    const int blk_cur = blk_next;
+    if (b + 4 < b_end) blk_next = bt[b + 4];
+    const int64_t page = ((int64_t)blk_cur * Hkv + kvh) * (PAGE_ELEMS * ESZ);
     bf16x8 kf[2][4];
     KLoader<KV8>::load(kc + page, col, g, kf);
     bf16x8 vf[8];
