@@ -114,6 +114,9 @@ class CacheConfig:
     block_size: int = KV_BLOCK_SIZE
     kv_dtype: str = "auto"              # "auto" (= model dtype) | "fp8" (OCP e4m3, per-layer per-kv-head scales)
     calibrate_fp8_scales: bool = True   # fp8: set the scales from a warm-up prefill (amax / 448); False keeps 1.0
+    # fp8: text file whose content (tokenised with the served tokenizer) is the calibration stream instead of random
+    # token ids — real prompts put attention sinks / first-token outliers where they occur in service
+    calibration_file: Optional[str] = None
     num_blocks: Optional[int] = None    # None → size from free HBM after weights + activation peak
     gpu_memory_utilization: float = 0.92
     enable_prefix_caching: bool = True

@@ -22,7 +22,7 @@
 //   4. barrier "end": nobody may overwrite staging/result before every peer has finished reading.
 // Flags are system-scope release/acquire atomics on *uncached* memory (hipExtMallocWithFlags); data
 // stores are followed by a system-scope release fence before the flag that publishes them.  Every spin is
-// bounded: on timeout the kernel raises `error` in its Signal block and finishes.  The host copies
+// bounded: on timeout the kernel raises `error` in the Signal block of every rank and finishes.  The host copies
 // that word back behind every step (`ar_error_async`, no synchronisation) and, when it is set,
 // switches the whole TP group to the library collectives for good — a lost peer can never hang the GPU.
 // Flags are compared as "epoch reached" (signed distance ≥ 0), so a rank that timed out once cannot
@@ -93,7 +93,10 @@ __device__ __forceinline__ void mesh_barrier(const Peers& p, int rank, int world
     unsigned spins = 0;
     while ((int32_t)(__hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - flag) < 0) {
       if (++spins > kSpinLimit) {
-        __hip_atomic_store(&self->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // raised in EVERY rank's signal block: the sums of this call are partial on whoever reads this rank's data, so
+        // each rank's host must learn of the fault with the step it happened in (the driver discards that step)
+        for (int r = 0; r < world; ++r)
+          __hip_atomic_store(&p.signal[r]->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
       __builtin_amdgcn_s_sleep(2);

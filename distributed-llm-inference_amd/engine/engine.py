@@ -44,6 +44,7 @@ class LLMEngine:
             self.bm = BlockManager(self.runner.num_blocks, KV_BLOCK_SIZE, cfg.cache.enable_prefix_caching)
             self.scheduler = Scheduler(cfg.sched, self.bm)
             self.scheduler.seq_ids = self._seq_ids
+            self.scheduler.max_copies_per_step = ModelRunner.MAX_COW
         else:
             self.bm = None
             self.scheduler = None
@@ -164,8 +165,14 @@ class LLMEngine:
             self.requests.pop(req.req_id, None)
             self.metrics.on_finish(req, aborted=True)
             self.metrics.requests_shed += 1
-            outs.append(RequestOutput(req.req_id, [], True, RequestStatus.FINISHED_SHED.value, req.num_prompt, 0, 0,
-                                      req.client_tag, req.parent_id, req.sample_index))
+            # an n > 1 parent that never got to fork answers for ALL its choices: the client's stream ends only after
+            # n finished records (AsyncEngine.generate), and the children that would send the others do not exist
+            choices = range(req.n_samples) if (req.n_samples > 1 and not req.forked) else (req.sample_index,)
+            req.forked = True
+            for c in choices:
+                outs.append(RequestOutput(req.req_id if c == req.sample_index else f"{req.req_id}#{c}", [], True,
+                                          RequestStatus.FINISHED_SHED.value, req.num_prompt, 0, 0, req.client_tag,
+                                          req.parent_id if c == req.sample_index else req.req_id, c))
         self.scheduler.shed.clear()
         return outs
 
@@ -174,6 +181,8 @@ class LLMEngine:
         t1 = time.perf_counter()
         with trace_range("collect"):
             sampled = self.runner.collect(handle)
+        if self.runner.take_comm_fault():
+            return self._recover_from_comm_fault(batch)
         t2 = time.perf_counter()
         with trace_range("update"):
             results = self.scheduler.resolve(batch, sampled, self.cfg.model.eos_token_id)
@@ -201,6 +210,25 @@ class LLMEngine:
         self.scheduler.observe_step(dt, batch.total_tokens)
         return outs
 
+    def _recover_from_comm_fault(self, batch) -> list[RequestOutput]:
+        """The step just collected ran a custom all-reduce that timed out (on this or — the kernels raise the flag in
+        every peer's signal block — on any other rank): its sums, hence its sampled ids and the K/V it wrote, are
+        garbage, and so is whatever the step queued behind it computed on top.  Neither step's tokens reach the
+        clients: both are discarded and every sequence holding pages is recomputed (``Scheduler.reset_after_fault``).
+        The group leaves the custom kernels with the next step header (``ModelRunner._broadcast_step``)."""
+        batches = [batch]
+        if self._inflight is not None:                       # queued behind the faulty step: drain it, drop it
+            nxt, handle = self._inflight[0], self._inflight[1]
+            self._inflight = None
+            self.runner.collect(handle)
+            self.runner.take_comm_fault()
+            batches.append(nxt)
+        n = self.scheduler.reset_after_fault(batches)
+        self.metrics.comm_fault_recoveries += 1
+        self._last_result_time = 0.0
+        print(f"[dli_amd] all-reduce fault: discarded {len(batches)} step(s), recomputing {n} sequence(s)", flush=True)
+        return []
+
     # ------------------------------------------------------------------ conveniences
     def generate(self, prompts, params: Optional[SamplingParams] = None, prompt_ids=None) -> list[list[int]]:
         """Offline helper: run a list of prompts to completion, return the generated ids per prompt."""
@@ -224,7 +252,11 @@ class LLMEngine:
         self._warmed = True
         self.ctx.barrier()
         if self.cfg.cache.kv_dtype == "fp8" and self.cfg.cache.calibrate_fp8_scales:
-            self.runner.calibrate_kv_scales()
+            ids = None
+            if self.cfg.cache.calibration_file:
+                with open(self.cfg.cache.calibration_file, encoding="utf-8", errors="replace") as fh:
+                    ids = np.asarray(self.tokenizer.encode(fh.read()), dtype=np.int64) % self.cfg.model.vocab_size
+            self.runner.calibrate_kv_scales(ids if ids is not None and len(ids) >= 16 else None)
         if capture_graphs:
             self.runner.capture_all()
         self.runner.startup_selftest()

@@ -41,6 +41,7 @@ class EngineMetrics:
         self.requests_finished = 0
         self.requests_aborted = 0
         self.requests_shed = 0
+        self.comm_fault_recoveries = 0
         self.prompt_tokens = 0
         self.cached_prompt_tokens = 0
         self.generated_tokens = 0
@@ -102,6 +103,7 @@ class EngineMetrics:
             ("dli_requests_finished_total", "counter", "requests completed", self.requests_finished),
             ("dli_requests_aborted_total", "counter", "requests aborted (client disconnect)", self.requests_aborted),
             ("dli_requests_shed_total", "counter", "requests dropped by overload shedding (max_queue_delay)", self.requests_shed),
+            ("dli_comm_fault_recoveries_total", "counter", "steps discarded after an all-reduce time-out (sequences recomputed)", self.comm_fault_recoveries),
             ("dli_prompt_tokens_total", "counter", "prompt tokens received", self.prompt_tokens),
             ("dli_prefix_cache_hit_tokens_total", "counter", "prompt tokens served from the prefix cache", self.cached_prompt_tokens),
             ("dli_generated_tokens_total", "counter", "tokens generated", self.generated_tokens),

@@ -52,6 +52,7 @@ class Scheduler:
         self.pending_copies: list[tuple[int, int]] = []    # (src page, dst page) copy-on-write work for the next launch
         self.seq_ids = None                                # iterator of fresh sequence ids (set by the engine)
         self.shed: list[Request] = []                      # finished with status "shed"; the engine reports them
+        self.max_copies_per_step = 256                     # copy-on-write pairs one launch takes (ModelRunner.MAX_COW)
         self.num_shed = 0
         # TPOT controller state
         self.dyn_budget = cfg.max_num_batched_tokens        # current total-token target of a step
@@ -105,6 +106,42 @@ class Scheduler:
         self.num_preemptions += 1
         self.waiting.appendleft(req)
 
+    def reset_after_fault(self, batches) -> int:
+        """A step's results cannot be trusted (a tensor-parallel all-reduce kernel gave up waiting for a peer and
+        finished with partial sums): nothing computed by the steps in ``batches`` — sampled ids, K/V written to the
+        pages, pages published to the prefix cache — may be used.  Every sequence that holds pages goes back to the
+        waiting queue for recomputation from the tokens the host already knew before those steps (placeholders of
+        in-flight samples are dropped), and the prefix cache is emptied.  Returns the number of sequences reset."""
+        victims = list(self.running)
+        seen = {id(r) for r in victims}
+        for b in batches:
+            for r in b.requests:                            # taken out of `running` at launch (length limit reached)
+                if id(r) not in seen and r.finishing and not r.status.finished:
+                    victims.append(r)
+                    seen.add(id(r))
+        for r in victims:
+            if self.bm.has_seq(r.seq_id):
+                self.bm.free_seq(r.seq_id)                  # no commit: the pages may hold garbage
+            r.num_tokens -= r.pending
+            r.pending = 0
+            r.finishing = False
+            r.sample_row = -1
+            r.num_computed = 0
+            r.status = RequestStatus.PREEMPTED
+            r.preemptions += 1
+        self.running.clear()
+        self.pending_copies.clear()
+        for q in (self.waiting, self.late):                 # a prefix matched but not admitted holds references too
+            for r in q:
+                if self.bm.has_seq(r.seq_id):
+                    self.bm.free_seq(r.seq_id)
+                    r.num_computed = 0
+        self.bm.reset_prefix_cache()
+        victims.sort(key=lambda r: r.arrival)
+        self.waiting.extendleft(reversed(victims))
+        self.num_preemptions += len(victims)
+        return len(victims)
+
     # ------------------------------------------------------------------ TPOT control
     def observe_step(self, seconds: float, tokens: int) -> None:
         """Feedback from the engine: wall time of a finished step and the tokens it computed.  Multiplicative
@@ -127,8 +164,10 @@ class Scheduler:
         if lim is None:
             return
         for q in (self.late, self.waiting):
-            # arrival order: overdue requests sit at the head; preempted/partly generated ones are never shed
-            while q and q[0].arrival < now - lim and q[0].num_output == 0 and q[0].preemptions == 0:
+            # arrival order: overdue requests sit at the head; preempted / partly generated ones and the queued
+            # children of an n > 1 request (their parent is being served) are never shed
+            while q and q[0].arrival < now - lim and q[0].num_output == 0 and q[0].preemptions == 0 \
+                    and q[0].parent_id is None:
                 req = q.popleft()
                 if self.bm.has_seq(req.seq_id):
                     self.bm.free_seq(req.seq_id)
@@ -187,7 +226,7 @@ class Scheduler:
         if cfg.ttft_slo is not None and self.waiting:
             deadline = now - cfg.ttft_slo * (1.0 - cfg.ttft_slo_margin)
             while self.waiting and self.waiting[0].arrival < deadline and self.waiting[0].num_output == 0 \
-                    and self.waiting[0].preemptions == 0:
+                    and self.waiting[0].preemptions == 0 and self.waiting[0].parent_id is None:
                 self.late.append(self.waiting.popleft())    # arrival order = deadline order: late ones sit at the head
         if not preempted and admit:
             while (self.waiting or self.late) and budget > 0 and prefill_left > 0 and len(self.running) < cfg.max_num_seqs:
@@ -264,13 +303,18 @@ class Scheduler:
         req.forked = True
         k = req.n_samples - 1
         room = self.bm.num_free - self.watermark_blocks >= k
+        queued = []
         for i in range(1, req.n_samples):
             child = Request(f"{req.req_id}#{i}", next(self.seq_ids), req.tokens[:req.num_prompt],
                             dataclasses.replace(req.params), req.arrival, req.client_tag)
             child.seed = (req.seed + 0x9E3779B1 * i) & 0x7FFFFFFF
             child.parent_id, child.sample_index = req.req_id, i
             child.first_scheduled = req.first_scheduled
-            if room:
+            # a child joins the running set only while the step buffers have a row for it (they are sized to
+            # max_num_seqs: every running sequence is scheduled every step) and this step's copy-on-write list has a
+            # slot; the others queue at the HEAD of the waiting line (they belong to an admitted request) and skip the
+            # shared prompt through the prefix cache when their turn comes
+            if room and len(self.running) < self.cfg.max_num_seqs and len(self.pending_copies) < self.max_copies_per_step:
                 self.bm.fork(req.seq_id, child.seq_id)
                 src, dst = self.bm.cow_tail(child.seq_id, req.num_prompt - 1)
                 if src >= 0:
@@ -279,8 +323,9 @@ class Scheduler:
                 child.status = RequestStatus.RUNNING
                 self.running.append(child)
             else:
-                self.waiting.append(child)
+                queued.append(child)
             self.forked.append(child)
+        self.waiting.extendleft(reversed(queued))
 
     def take_copies(self) -> list:
         out, self.pending_copies = self.pending_copies, []

@@ -71,7 +71,9 @@ class Attention(nn.Module):
         # (ModelRunner.calibrate_kv_scales); the kernels read them at run time, so decode graphs see updates
         self.kv_scales = None
         self.calibrating = False
+        self.measuring = False            # held-out pass: count the values the calibrated scales would clip
         self._calibrated = False
+        self.sat_count = self.sat_total = None
 
     def enable_kv_scales(self, device):
         self.kv_scales = torch.ones(2, self.hkv, dtype=torch.float32, device=device)
@@ -88,11 +90,25 @@ class Attention(nn.Module):
         self.kv_scales.copy_(torch.maximum(self.kv_scales, new) if self._calibrated else new)
         self._calibrated = True
 
+    @torch.no_grad()
+    def _measure(self, qkv):
+        """Held-out pass after calibration: how many K / V elements exceed the e4m3 range under the current scales
+        (they are clamped to ±448 by the cache write)."""
+        T, hq, hkv, d = qkv.shape[0], self.hq, self.hkv, self.d
+        k = qkv[:, hq * d:(hq + hkv) * d].float().view(T, hkv, 2, d // 2).pow(2).sum(2).sqrt()
+        v = qkv[:, (hq + hkv) * d:].float().view(T, hkv, d).abs()
+        lim = self.kv_scales * 448.0
+        n = (k > lim[0].view(1, hkv, 1)).sum() + (v > lim[1].view(1, hkv, 1)).sum()
+        self.sat_count = n if self.sat_count is None else self.sat_count + n
+        self.sat_total = (self.sat_total or 0) + k.numel() + v.numel()
+
     def forward(self, h, meta, kv, cos_sin):
         qkv = self.qkv(h)
         k_cache, v_cache = kv
         if self.calibrating and self.kv_scales is not None:
             self._observe(qkv)
+        elif self.measuring and self.kv_scales is not None:
+            self._measure(qkv)
         ops.rope_and_cache(qkv, meta.positions, cos_sin if self.rope else None, meta.slot_mapping, k_cache, v_cache,
                            self.hq, self.hkv, self.d, self.k_scale, self.v_scale, self.kv_scales)
         a = ops.paged_attention(qkv, k_cache, v_cache, meta, self.hq, self.hkv, self.d, self.scale,

@@ -78,6 +78,7 @@ class ModelRunner:
         self.selftest: dict = {}                             # start-up checks of the fast paths → what got disabled
         self._dumped = False
         self._ar_vote = 0                                    # this rank saw its all-reduce kernel time out
+        self._comm_fault = False                             # driver: the step just collected cannot be trusted
         self.ctx.barrier()                                   # weights loaded everywhere before the first collective
 
     # ------------------------------------------------------------------ sizing
@@ -263,7 +264,13 @@ class ModelRunner:
         ar = self.ctx.custom_ar
         if ar is not None and ar.enabled and not self._ar_vote and ar.error_seen:
             self._ar_vote = 1                                # travels with the next step header; the group switches together
+            self._comm_fault = True                          # the engine discards this step and what is queued behind it
             print(f"[dli_amd] tp rank {self.ctx.tp_rank}: custom all-reduce timed out waiting for a peer", flush=True)
+
+    def take_comm_fault(self) -> bool:
+        """True once after a collected step was found to contain a timed-out all-reduce (``LLMEngine._finish_step``)."""
+        f, self._comm_fault = self._comm_fault, False
+        return f
 
     def execute(self, batch, bm) -> np.ndarray:
         return self.collect(self.launch(batch, bm))
@@ -447,7 +454,7 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ fp8 KV calibration
     @torch.inference_mode()
-    def calibrate_kv_scales(self, prompt_ids=None, num_tokens: int = 2048) -> dict:
+    def calibrate_kv_scales(self, prompt_ids=None, num_tokens: int = 2048, held_out=None) -> dict:
         """fp8 (e4m3) KV cache: set every layer's per-kv-head K and V scales from one warm-up prefill (amax / 448 with 20 %
         head-room) instead of the unit scale — with unit scales small K/V values fall into e4m3's subnormals.  Runs the
         normal forward over ``prompt_ids`` (default: ``num_tokens`` random ids) into scratch pages 0…; each attention
@@ -469,19 +476,25 @@ class ModelRunner:
             ids = np.random.default_rng(1234).integers(3, self.cfg.model.vocab_size, size=T)
         else:
             ids = np.asarray(prompt_ids[:T])
-        nb = (T + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
-        nv = self.nv
-        self.n_input[:T] = ids
-        self.n_pos[:T] = np.arange(T)
-        self.n_slot[:T] = np.arange(T)                       # pages 0 … nb-1, in order
-        self.n_bt[0, :nb] = np.arange(nb)
-        self.n_seq_lens[0] = T
-        self.n_qsl[:2] = (0, T)
-        ts, t0 = ops.build_prefill_tiles(np.array([T], dtype=np.int32), 0, self.tile_tokens)
-        nv["tile_seq"][:len(ts)] = ts
-        nv["tile_q0"][:len(ts)] = t0
-        self._copy_in()
-        meta = self._meta(1, T, 0, 0, 1, len(ts))
+            if held_out is None and len(prompt_ids) >= T + 16:
+                held_out = np.asarray(prompt_ids[T:2 * T])
+        def stage(tok):
+            n = len(tok)
+            nb = (n + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+            nv = self.nv
+            self.n_input[:n] = tok
+            self.n_pos[:n] = np.arange(n)
+            self.n_slot[:n] = np.arange(n)                   # pages 0 … nb-1, in order
+            self.n_bt[0, :nb] = np.arange(nb)
+            self.n_seq_lens[0] = n
+            self.n_qsl[:2] = (0, n)
+            ts, t0 = ops.build_prefill_tiles(np.array([n], dtype=np.int32), 0, self.tile_tokens)
+            nv["tile_seq"][:len(ts)] = ts
+            nv["tile_q0"][:len(ts)] = t0
+            self._copy_in()
+            return self._meta(1, n, 0, 0, 1, len(ts))
+
+        meta = stage(ids)
         for a in attns:
             a.calibrating, a._calibrated = True, False
         try:
@@ -489,11 +502,31 @@ class ModelRunner:
         finally:
             for a in attns:
                 a.calibrating = False
+        # held-out check: a second stream (the prompt's unused tail, else fresh random ids) through the calibrated
+        # model — the share of K/V values beyond the e4m3 range under these scales is what the cache write will clip
+        if held_out is None:
+            held_out = np.random.default_rng(4321).integers(3, self.cfg.model.vocab_size, size=T)
+        held_out = np.asarray(held_out[:T])
+        sat = None
+        if len(held_out):
+            meta = stage(held_out)
+            for a in attns:
+                a.measuring, a.sat_count, a.sat_total = True, None, None
+            try:
+                self.model(self.dv["input"][:len(held_out)], meta, self.kv_caches)
+            finally:
+                for a in attns:
+                    a.measuring = False
+            tot = sum(a.sat_total or 0 for a in attns)
+            cnt = sum(float(a.sat_count) for a in attns if a.sat_count is not None)
+            sat = cnt / max(tot, 1)
         if self.on_gpu:
             torch.cuda.synchronize()
         sc = torch.stack([a.kv_scales for a in attns]).float().cpu()          # [layers, 2, Hkv]
-        self.selftest["fp8_kv_scales"] = {"tokens": int(T), "k_scale_min": float(sc[:, 0].min()), "k_scale_max": float(sc[:, 0].max()),
-                                          "v_scale_min": float(sc[:, 1].min()), "v_scale_max": float(sc[:, 1].max())}
+        self.selftest["fp8_kv_scales"] = {"tokens": int(T), "source": "prompts" if prompt_ids is not None else "random ids",
+                                          "k_scale_min": float(sc[:, 0].min()), "k_scale_max": float(sc[:, 0].max()),
+                                          "v_scale_min": float(sc[:, 1].min()), "v_scale_max": float(sc[:, 1].max()),
+                                          "held_out_saturation_rate": sat}
         return self.selftest["fp8_kv_scales"]
 
     @torch.inference_mode()

@@ -341,7 +341,8 @@ def engine_config_from_args(a) -> EngineConfig:
     return EngineConfig(
         model=get_model_config(a.model, **overrides),
         cache=CacheConfig(kv_dtype=a.kv_dtype, num_blocks=a.num_kv_blocks, gpu_memory_utilization=a.gpu_memory_utilization,
-                          enable_prefix_caching=not a.no_prefix_caching),
+                          enable_prefix_caching=not a.no_prefix_caching,
+                          calibration_file=getattr(a, "kv_calibration_file", None)),
         sched=SchedulerConfig(max_num_seqs=a.max_num_seqs, max_num_batched_tokens=a.max_num_batched_tokens,
                               max_model_len=a.max_model_len, long_prefill_chunk=a.prefill_chunk, ttft_slo=a.ttft_slo,
                               tpot_slo=a.tpot_slo, max_queue_delay=a.max_queue_delay),
@@ -358,6 +359,8 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--tp", type=int, default=1)
     ap.add_argument("--ep", type=int, default=1)
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"])
+    ap.add_argument("--kv-calibration-file", default=None,
+                    help="fp8 KV: text file of representative prompts to calibrate the per-head scales on (default: random ids)")
     ap.add_argument("--num-kv-blocks", type=int, default=None)
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
     ap.add_argument("--no-prefix-caching", action="store_true")

@@ -461,3 +461,92 @@ def test_decode_rows_are_ordered_longest_context_first():
     assert b.num_decode == 4
     ctx = [r.num_computed for r in b.requests[:b.num_decode]]
     assert ctx == sorted(ctx, reverse=True) and len(set(ctx)) == 4
+
+
+def test_n_samples_never_exceed_the_sequence_cap():
+    """a request with n > 1 completing its prompt while the replica is at max_num_seqs must not push
+    the running set past the cap (the step buffers have max_num_seqs rows) — the extra children queue at the head of
+    the waiting line and still produce the parent's greedy continuation."""
+    eng = make_engine(max_seqs=2, max_tokens=128, num_blocks=64)
+    greedy = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True)
+    rng = np.random.default_rng(5)
+    other = rng.integers(3, 500, size=20).tolist()
+    prompt = rng.integers(3, 500, size=40).tolist()
+    want = make_engine(max_seqs=2, max_tokens=128).generate(None, greedy, prompt_ids=[prompt])[0]
+    eng.add_request("other", prompt_ids=other, params=SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True))
+    eng.step()
+    eng.add_request("r", prompt_ids=prompt, params=greedy, n=4)
+    outs, peak = {}, 0
+    for _ in range(600):
+        if not eng.has_unfinished():
+            break
+        for o in eng.step():
+            outs.setdefault((o.parent_id or o.req_id, o.sample_index), []).extend(o.new_token_ids)
+        peak = max(peak, len(eng.scheduler.running))
+    assert not eng.has_unfinished() and peak <= 2
+    assert all(outs[("r", i)] == want for i in range(4)), outs
+    assert eng.bm.num_free == eng.bm.num_blocks and not eng.requests
+
+
+def test_copy_on_write_overflow_queues_children_instead_of_raising():
+    eng = make_engine(max_seqs=8, max_tokens=128, num_blocks=64)
+    eng.scheduler.max_copies_per_step = 1
+    greedy = SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True)
+    eng.add_request("r", prompt_ids=list(range(3, 43)), params=greedy, n=4)
+    done = {}
+    for _ in range(200):
+        if not eng.has_unfinished():
+            break
+        for o in eng.step():
+            done.setdefault(o.sample_index, []).extend(o.new_token_ids)
+    assert len(done) == 4 and len({tuple(v) for v in done.values()}) == 1
+    assert eng.bm.num_free == eng.bm.num_blocks
+
+
+def test_shed_parent_with_n_samples_reports_every_choice():
+    """a parent shed before it forked must close all n choices (the stream waits for n finishes)."""
+    import time as _t
+    eng = make_engine(max_seqs=1, max_tokens=64)
+    eng.cfg.sched.max_queue_delay = 0.05
+    long = SamplingParams(temperature=0.0, max_tokens=100, ignore_eos=True)
+    eng.add_request("busy", prompt_ids=[5, 6, 7], params=long)
+    eng.step()
+    eng.add_request("r", prompt_ids=[9, 10, 11], params=SamplingParams(temperature=0.0, max_tokens=4), n=3)
+    _t.sleep(0.08)
+    shed = []
+    for _ in range(5):
+        shed += [(o.parent_id or o.req_id, o.sample_index, o.finish_reason) for o in eng.step() if o.finished]
+    assert sorted(shed) == [("r", 0, "shed"), ("r", 1, "shed"), ("r", 2, "shed")]
+    assert "r" not in eng.requests
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_comm_fault_discards_the_suspect_steps_and_recomputes(pipelined):
+    """when a step turns out to contain a timed-out all-reduce, neither its tokens nor those of the
+    step queued behind it reach the client, the pages they wrote are not published, and the output equals a clean run."""
+    greedy = SamplingParams(temperature=0.0, max_tokens=16, ignore_eos=True)
+    rng = np.random.default_rng(11)
+    prompts = [rng.integers(3, 500, size=n).tolist() for n in (40, 70, 9)]
+    want = make_engine(async_scheduling=pipelined).generate(None, greedy, prompt_ids=prompts)
+
+    eng = make_engine(async_scheduling=pipelined)
+    calls = {"n": 0}
+    real = eng.runner.collect
+
+    def collect(handle):
+        out = real(handle)
+        calls["n"] += 1
+        if calls["n"] == 6:                                  # mid-generation: poison this step
+            eng.runner._comm_fault = True
+            out = np.full_like(out, 1)                       # what a partial sum would look like: wrong ids
+        return out
+    eng.runner.collect = collect
+    for i, p in enumerate(prompts):
+        eng.add_request(f"q{i}", prompt_ids=p, params=greedy)
+    got = {}
+    while eng.has_unfinished():
+        for o in eng.step():
+            got.setdefault(o.req_id, []).extend(o.new_token_ids)
+    assert [got[f"q{i}"] for i in range(3)] == want
+    assert eng.metrics.comm_fault_recoveries == 1
+    assert eng.bm.num_free == eng.bm.num_blocks
