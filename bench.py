@@ -24,14 +24,19 @@ every rank probes RCCL and the custom xGMI collectives in a throw-away child pro
 the probe's all-reduce latency table is embedded in the line.
 
 A *step* is one engine iteration (schedule → forward over the continuous batch → sample → advance).  Untimed:
-weight init, hipGraph capture, start-up self-tests, a ramp phase that runs the replay until the engine is in
-steady state, then ``--warmup`` steps.  Timed: exactly ``--steps`` steps between barrier + synchronize brackets;
-``value`` = requests that *finished inside the timed window* with TTFT and TPOT within the model's relaxed SLO
-(BASELINE.md §3), summed over replicas, divided by the max-over-ranks wall time.  A window shorter than 10 s or
-500 finished requests is a noisy sample of that rate: the line then carries ``window_too_short: true`` and
-``value_sustained`` — the same quantity over the last ``--sustained-seconds`` of real-time replay (ramp tail +
-warm-up + timed steps) with a 95 % confidence interval.  ``vs_baseline`` is null: the reference publishes no
-throughput figure to divide by (its only replay served 6 requests serially on unknown hardware).
+weight init, hipGraph capture, start-up self-tests, (``--tp`` > 1 without ``--qps``: a capacity probe that sets the
+offered load,) a ramp that replays until the engine IS in steady state — the population of requests in the system
+grows by less than 10 % of the arrivals over the last 10 s (``SteadyDetector``; at least ``--ramp-seconds``, at most
+``--ramp-cap-seconds``) — then ``--sustained-seconds`` more of replay, then ``--warmup`` steps.  Timed: exactly
+``--steps`` steps between barrier + synchronize brackets (``ms_per_step``); ``value_window`` = requests that
+*finished inside the timed window* with TTFT and TPOT within the model's relaxed SLO, summed over
+replicas, divided by the max-over-ranks wall time.  A window shorter than 10 s or 500 finished requests is a noisy
+sample of a rate (20 steps ≈ 1 s ≈ 60 requests): the line then carries ``window_too_short: true`` and ``value`` is
+``value_sustained`` — the same quantity over the last ``--sustained-seconds`` of real-time replay, ALL of it after the
+steady point and ending with the timed steps, with a 95 % confidence interval; otherwise ``value`` is the timed
+window's own figure.  ``steady`` says whether the criterion was met before the cap.  ``vs_baseline`` is null: the
+reference publishes no throughput figure to divide by (its only replay served 6 requests serially on
+unknown hardware).
 """
 from __future__ import annotations
 
@@ -66,10 +71,14 @@ def parse(argv=None):
     ap.add_argument("--qps", type=float, default=float(os.environ.get("DLI_BENCH_QPS", "0")),
                     help="offered load per replica (requests/s); 0: the model's default")
     ap.add_argument("--ramp-seconds", type=float, default=30.0,
-                    help="untimed replay before the window: ~2 request lifetimes, so that the in-flight population is steady")
-    ap.add_argument("--sustained-seconds", type=float, default=20.0)
-    ap.add_argument("--max-num-seqs", type=int, default=2048)
-    ap.add_argument("--max-batched-tokens", type=int, default=4096)
+                    help="shortest untimed replay before the window; the ramp goes on until the steady-state criterion holds")
+    ap.add_argument("--ramp-cap-seconds", type=float, default=120.0, help="longest ramp (the line then says steady: false)")
+    ap.add_argument("--sustained-seconds", type=float, default=20.0,
+                    help="replay between the steady point and the timed steps; value_sustained covers exactly this stretch")
+    ap.add_argument("--capacity-probe-seconds", type=float, default=20.0,
+                    help="--tp > 1 without --qps: saturate the replica this long, offer 0.9 × the measured completion rate")
+    ap.add_argument("--max-num-seqs", type=int, default=0, help="0: 2048, or 4096 for --tp > 2")
+    ap.add_argument("--max-batched-tokens", type=int, default=0, help="0: 4096, or 8192 for --tp > 2 (1/tp of the GEMM work per GPU)")
     ap.add_argument("--chunk", type=int, default=2048)
     ap.add_argument("--kv-dtype", default="auto")
     ap.add_argument("--slo", default="relaxed", choices=["relaxed", "interactive"], help="SLO row that defines `value`")
@@ -153,9 +162,16 @@ class Replay:
                     self.done.append(r)
 
     def run_for(self, seconds):
-        end = time.perf_counter() + seconds
+        self.run_until(time.perf_counter() + seconds)
+
+    def run_until(self, end):
         while time.perf_counter() < end:
             self.one_step()
+
+    @property
+    def population(self):
+        """Requests in the system (queued or running): injected − finished − shed."""
+        return self.nxt - len(self.done) - self.shed
 
     def drain(self):
         """Abort everything in flight (between sweep points)."""
@@ -165,6 +181,34 @@ class Replay:
         while eng.has_unfinished():
             eng.step()
         self.live.clear()
+
+
+class SteadyDetector:
+    """Ramp criterion (shared with the sweep's ``mark_steady``): the replay is in steady state when the number of
+    requests in the system grew by less than ``frac`` of the arrivals over the last ``horizon`` seconds — below that
+    the latencies being measured are the ones this load ends up with; above it the backlog is still building."""
+
+    def __init__(self, horizon=10.0, frac=0.10):
+        self.horizon, self.frac = horizon, frac
+        self.samples = []                                    # (t, population, arrivals so far)
+
+    def add(self, t, population, arrived):
+        self.samples.append((float(t), int(population), int(arrived)))
+
+    def growth(self):
+        """(population growth, arrivals) over the last ``horizon`` seconds, or None before that much was seen."""
+        if not self.samples:
+            return None
+        t1, p1, a1 = self.samples[-1]
+        old = [x for x in self.samples if x[0] <= t1 - self.horizon + 1e-9]
+        if not old:
+            return None
+        _, p0, a0 = old[-1]
+        return p1 - p0, a1 - a0
+
+    def steady(self):
+        g = self.growth()
+        return bool(g is not None and g[1] > 0 and g[0] < self.frac * g[1])
 
 
 def request_stats(reqs, slo):
@@ -229,7 +273,13 @@ def main():
 
     slo_rows = SLOS.get(args.model, SLOS["llama3-8b"])
     slo = slo_rows[args.slo]
+    # offered load per replica: --qps, else the model's measured 1-GPU rate; a TP replica without --qps measures its own
+    # capacity first (run_fixed → capacity_probe) — the figure here is then only the probe's starting point
     qps = args.qps or DEFAULT_QPS.get(args.model, 20.0) * (1.0 if args.tp == 1 else 0.6 * args.tp)
+    if not args.max_num_seqs:
+        args.max_num_seqs = 2048 if args.tp <= 2 else 4096
+    if not args.max_batched_tokens:
+        args.max_batched_tokens = 4096 if args.tp <= 2 else 8192
     over = {"num_layers": args.num_layers} if args.num_layers else {}
     mcfg = get_model_config(args.model, **over)
     qdelay = args.max_queue_delay if args.max_queue_delay is not None else 4.0 * slo[0]
@@ -259,13 +309,25 @@ def main():
         if job.driver_group is not None:
             dist.barrier(group=job.driver_group)
 
+    def agree(v, how):
+        """Drivers agree on a small integer: ``min`` of a value, or ``min_bits`` = AND of a bit mask (sum-free, 2 bits)."""
+        if job.driver_group is None:
+            return v
+        if how == "min":
+            t = torch.tensor([int(v)], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=job.driver_group)
+            return int(t[0])
+        t = torch.tensor([(v >> 1) & 1, v & 1], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=job.driver_group)
+        return (int(t[0]) << 1) | int(t[1])
+
     if not layout.is_driver:
         worker_loop(eng)                                     # returns when the replica's driver shuts the group down
         stats = None
     elif args.sweep:
         stats = run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers)
     else:
-        stats = run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu)
+        stats = run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu, agree, note)
     if layout.is_driver:
         eng.shutdown()
 
@@ -311,10 +373,39 @@ def make_share(args, mcfg, layout, qps, seconds, seed):
             np.minimum(mine["Response tokens"].to_numpy(), 1024))
 
 
-def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu):
+def capacity_probe(args, eng, mcfg, layout, qps_guess, sync_drivers, agree, note):
+    """Offered load for a replica nobody has measured yet (``--tp`` > 1 without ``--qps``): saturate it for
+    ``--capacity-probe-seconds`` (3 × the guess, shedding on), take the token rate of the second half and divide by the
+    trace's mean tokens per request → requests/s the replica can complete; offer 0.9 × the smallest replica's figure."""
     import numpy as np
+    secs = args.capacity_probe_seconds
+    stamps, n_in, n_out = make_share(args, mcfg, layout, 3.0 * qps_guess, secs + 5.0, args.seed + 991)
+    rp = Replay(eng, mcfg.vocab_size, stamps, n_in, n_out, args.seed * 1000 + 500 + layout.replica)
+    rp.tag = "cap"
+    sync_drivers()
+    rp.start(time.perf_counter())
+    rp.run_for(secs / 2)
+    tok0, t_a = eng.metrics.step_tokens, time.perf_counter()
+    rp.run_for(secs / 2)
+    tok_s = (eng.metrics.step_tokens - tok0) / max(time.perf_counter() - t_a, 1e-6)
+    rp.drain()
+    per_req = float(np.mean(n_in + n_out))
+    est = tok_s / per_req
+    est_all = agree(int(est * 1000), "min") / 1000.0
+    info = {"seconds": secs, "offered_qps_during_probe": round(3.0 * qps_guess, 3), "tok_per_s": round(tok_s, 1),
+            "mean_tokens_per_request": round(per_req, 1), "est_req_per_s": round(est, 3),
+            "est_req_per_s_min_over_replicas": round(est_all, 3), "offered_fraction": 0.9}
+    note(f"capacity probe: {tok_s:.0f} tok/s ≈ {est:.2f} req/s per replica → offering {0.9 * est_all:.2f}")
+    return max(0.9 * est_all, 0.05), info
+
+
+def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu, agree, note):
+    import numpy as np
+    probe = None
+    if layout.tp > 1 and not args.qps and args.capacity_probe_seconds > 0:
+        qps, probe = capacity_probe(args, eng, mcfg, layout, qps, sync_drivers, agree, note)
     # an upper bound of the replay length: the ramp plus the steps at a pessimistic 0.25 s each
-    horizon = args.ramp_seconds + (args.steps + args.warmup) * 0.25 + 60.0
+    horizon = args.ramp_cap_seconds + args.sustained_seconds + (args.steps + args.warmup) * 0.25 + 60.0
     stamps, n_in, n_out = make_share(args, mcfg, layout, qps, horizon, args.seed + 17)
     rp = Replay(eng, mcfg.vocab_size, stamps, n_in, n_out, args.seed * 1000 + layout.replica)
     ctx = eng.ctx
@@ -322,7 +413,28 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu)
     sync_drivers()
     t0 = time.perf_counter()
     rp.start(t0)
-    rp.run_for(args.ramp_seconds)                            # untimed ramp to steady state
+    # ---- untimed ramp: until the population is steady on EVERY replica (all drivers check at the same replay times)
+    det = SteadyDetector(horizon=min(10.0, max(args.ramp_seconds, 0.5)))
+    tick = min(2.5, det.horizon / 2)
+    k, steady = 0, False
+    det.add(0.0, 0, 0)
+    while True:
+        k += 1
+        rp.run_until(t0 + k * tick)
+        t = time.perf_counter() - t0
+        det.add(t, rp.population, rp.nxt)
+        ok = t >= args.ramp_seconds - 1e-6 and det.steady()
+        capped = t >= args.ramp_cap_seconds
+        verdict = agree((2 if ok else 0) + (1 if capped else 0), "min_bits")
+        if verdict & 2:
+            steady = True
+            break
+        if verdict & 1:
+            break
+    t_steady = time.perf_counter()
+    growth = det.growth()
+    # ---- the sustained stretch: all of it after the steady point
+    rp.run_until(t_steady + args.sustained_seconds)
     for _ in range(args.warmup):
         rp.one_step()
     sync_drivers()
@@ -346,8 +458,9 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu)
     _, _, ok_i = request_stats(fin, slo_rows["interactive"])
     _, _, ok_r = request_stats(fin, slo_rows["relaxed"])
     comm_delta = {k: ctx.comm[k] - before[6][k] for k in ctx.comm}
-    sus = sustained(rp.done, t_end, args.sustained_seconds, slo) \
-        if t_end - t0 >= args.sustained_seconds else None
+    # everything between the steady point and the end of the timed steps (whole seconds, counted back from the end)
+    sus_s = int(t_end - t_steady)
+    sus = sustained(rp.done, t_end, sus_s, slo) if sus_s >= 1 else None
     stats = {
         "replica": layout.replica, "elapsed": elapsed, "finished": len(fin), "good": int(ok.sum()),
         "good_interactive": int(ok_i.sum()), "good_relaxed": int(ok_r.sum()),
@@ -362,7 +475,9 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu)
         "running": m.running, "waiting": m.waiting, "kv_used": m.kv_used_frac, "preemptions": m.preemptions,
         "backlog_s": float(time.perf_counter() - t0 - (stamps[rp.nxt - 1] if rp.nxt else 0.0)),
         "arrived": rp.nxt - n_inj_before, "late_queue": len(eng.scheduler.late), "comm": comm_delta,
-        "sustained": sus, "replay_seconds": t_end - t0,
+        "sustained": sus, "replay_seconds": t_end - t0, "steady": steady, "ramp_seconds": t_steady - t0,
+        "ramp_population": rp.population, "ramp_growth": list(growth) if growth else None,
+        "capacity_probe": probe, "offered_qps_per_replica": qps,
     }
     if args.dump and layout.rank == 0:
         with open(args.dump, "w") as fh:
@@ -374,6 +489,7 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu)
 
 def fixed_line(args, allstats, layout, slo, qps, mcfg):
     import numpy as np
+    qps = allstats[0].get("offered_qps_per_replica", qps)   # the capacity probe may have replaced the default
     T = max(s["elapsed"] for s in allstats)
     all_ttft = np.concatenate([np.array(s["ttft"]) for s in allstats])
     all_tpot = np.concatenate([np.array(s["tpot"]) for s in allstats])
@@ -421,8 +537,15 @@ def fixed_line(args, allstats, layout, slo, qps, mcfg):
                   if k not in ("ttft", "tpot", "sustained", "comm")},
     }
     line["window_too_short"] = bool(T < 10.0 or finished < 500)
+    line["value_window"] = line["value"]
+    line["steady"] = bool(all(s["steady"] for s in allstats))
+    line["ramp_s"] = round(max(s["ramp_seconds"] for s in allstats), 1)
+    line["population_growth_vs_arrivals_at_ramp_end"] = allstats[0]["ramp_growth"]
+    if allstats[0].get("capacity_probe"):
+        line["capacity_probe"] = allstats[0]["capacity_probe"]
     if all(s["sustained"] is not None for s in allstats):
-        bins = np.sum([np.array(s["sustained"]["good_per_bin"]) for s in allstats], axis=0)
+        nb = min(len(s["sustained"]["good_per_bin"]) for s in allstats)      # replicas may differ by a second
+        bins = np.sum([np.array(s["sustained"]["good_per_bin"][:nb]) for s in allstats], axis=0)
         st = np.concatenate([np.array(s["sustained"]["ttft"]) for s in allstats])
         sp = np.concatenate([np.array(s["sustained"]["tpot"]) for s in allstats])
         line.update({
@@ -432,6 +555,12 @@ def fixed_line(args, allstats, layout, slo, qps, mcfg):
             "sustained_ttft_p50_s": pct(st, 50), "sustained_ttft_p99_s": pct(st, 99),
             "sustained_tpot_p50_s": pct(sp, 50), "sustained_tpot_p99_s": pct(sp, 99),
         })
+        if line["window_too_short"]:
+            # K steps are a second or so of replay: the rate over the steady stretch that ENDS with them is the figure
+            line["value"] = line["value_sustained"]
+            line["value_source"] = (f"value_sustained: last {len(bins)} s of replay, all after the steady point "
+                                    f"(the {args.steps}-step window alone is value_window)")
+    line.setdefault("value_source", "timed window")
     return line
 
 

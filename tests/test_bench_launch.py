@@ -9,14 +9,14 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-COMMON = ["--device", "cpu", "--steps", "25", "--warmup", "2", "--ramp-seconds", "2", "--sustained-seconds", "2",
+COMMON = ["--device", "cpu", "--steps", "25", "--warmup", "2", "--ramp-seconds", "2", "--ramp-cap-seconds", "6", "--sustained-seconds", "2",
           "--qps", "8", "--max-num-seqs", "16", "--max-batched-tokens", "256", "--num-kv-blocks", "512"]
 
 
-def run_bench(extra, launcher=None, timeout=300):
+def run_bench(extra, launcher=None, timeout=300, common=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "2"
-    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra + COMMON
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + extra + (COMMON if common is None else common)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     return p, lines
@@ -31,7 +31,8 @@ def test_self_launch_dp2():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["self_launched"] is True
     assert d["vs_baseline"] is None and d["window_too_short"] is True and "value_sustained" in d
     assert d["backend"]["control"] == "gloo" and d["device_ids"] == [-1, -1]
-    assert d["requests_finished"] > 0 and d["steps"] == 25
+    assert d["sustained_n"] > 0 and d["steps"] == 25         # (the 25-step window itself is ≈ 0.2 s on CPU)
+    assert d["value"] == d["value_sustained"] and "value_window" in d and isinstance(d["steady"], bool)
 
 
 def test_self_launch_tp2_reports_collectives():
@@ -97,7 +98,7 @@ def test_world_size_8_layouts(extra, par):
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == par and d["requests_finished"] > 0
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == par and d["sustained_n"] > 0
     assert len(d["device_ids"]) == 8
     if "ep8" in par:
         assert d["comm_per_step"]["a2a_calls"] > 0      # prefill-sized steps dispatched by all-to-all over 8 ranks
@@ -120,3 +121,38 @@ def test_layout_rank_grouping(monkeypatch):
     for bad in (dict(gpus=4), dict(gpus=8, tp=3), dict(gpus=8, tp=4, ep=2)):
         with pytest.raises(SystemExit):
             Layout.from_env(**bad)
+
+
+def test_steady_detector_ramp_criterion():
+    """bench.py's ramp criterion: steady once the in-system population grew by < 10 % of the
+    arrivals over the last 10 s; never before a full horizon has been seen."""
+    sys.path.insert(0, ROOT)
+    import bench
+    d = bench.SteadyDetector(horizon=10.0, frac=0.10)
+    d.add(0.0, 0, 0)
+    for t in range(1, 10):
+        d.add(float(t), 60 * t, 68 * t)                      # almost nothing finishes yet: population tracks arrivals
+        assert not d.steady()
+    d.add(10.0, 600, 680)
+    assert d.growth() == (600, 680) and not d.steady()
+    for t in range(11, 40):                                  # completions catch up: growth decays
+        d.add(float(t), 600 + int(400 * (1 - 0.85 ** (t - 10))), 68 * t)
+    assert d.steady()
+    g, a = d.growth()
+    assert a == 680 and g < 68
+    e = bench.SteadyDetector(horizon=10.0)                   # overload: the backlog keeps growing by 30 % of the arrivals
+    for t in range(0, 60):
+        e.add(float(t), 20 * t, 68 * t)
+    assert not e.steady()
+
+
+def test_tp_replica_without_qps_probes_its_capacity_and_reports_steady_fields():
+    common = [x for i, x in enumerate(COMMON) if x != "--qps" and COMMON[i - 1] != "--qps"]
+    p, lines = run_bench(["--gpus", "2", "--tp", "2", "--model", "tiny-llama", "--capacity-probe-seconds", "2"], common=common)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(lines[0])
+    cp = d["capacity_probe"]
+    assert cp["est_req_per_s"] > 0 and d["config"]["offered_qps"] == pytest.approx(0.9 * cp["est_req_per_s_min_over_replicas"], rel=1e-2)
+    assert isinstance(d["steady"], bool) and d["ramp_s"] >= 2.0 and "value_window" in d
+    assert d["value"] == d["value_sustained"] and d["value_source"].startswith("value_sustained")
+    assert d["config"]["max_num_batched_tokens"] == 256
