@@ -73,8 +73,9 @@ def parse(argv=None):
     ap.add_argument("--ramp-seconds", type=float, default=30.0,
                     help="shortest untimed replay before the window; the ramp goes on until the steady-state criterion holds")
     ap.add_argument("--ramp-cap-seconds", type=float, default=120.0, help="longest ramp (the line then says steady: false)")
-    ap.add_argument("--sustained-seconds", type=float, default=20.0,
-                    help="replay between the steady point and the timed steps; value_sustained covers exactly this stretch")
+    ap.add_argument("--sustained-seconds", type=float, default=60.0,
+                    help="replay between the steady point and the timed steps; value_sustained covers exactly this stretch "
+                         "(the trace's arrival rate swings ±15 %% between 10 s bins: 60 s average that out to ≈ ±3 %%)")
     ap.add_argument("--capacity-probe-seconds", type=float, default=20.0,
                     help="--tp > 1 without --qps: saturate the replica this long, offer 0.9 × the measured completion rate")
     ap.add_argument("--max-num-seqs", type=int, default=0, help="0: 2048, or 4096 for --tp > 2")
@@ -87,6 +88,7 @@ def parse(argv=None):
     ap.add_argument("--max-queue-delay", type=float, default=None,
                     help="shed requests not admitted after this many seconds (default: 4 × the TTFT SLO)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-mixed-graphs", action="store_true", help="capture pure-decode steps only (A/B of the mixed-step graphs)")
     ap.add_argument("--no-custom-ar", action="store_true")
     ap.add_argument("--fcfs", action="store_true", help="plain FCFS admission (default: requests past their TTFT deadline yield)")
     ap.add_argument("--sync-steps", action="store_true", help="disable pipelined stepping (one step in flight at a time)")
@@ -293,7 +295,7 @@ def main():
                        parallel=ParallelConfig(tp=args.tp, ep=args.ep, custom_all_reduce=not args.no_custom_ar,
                                                ep_a2a_min_tokens=args.ep_a2a_min_tokens),
                        device=args.device, seed=args.seed, use_hip_graphs=on_gpu and not args.no_graphs,
-                       async_scheduling=False if args.sync_steps else None)
+                       async_scheduling=False if args.sync_steps else None, mixed_step_graphs=not args.no_mixed_graphs)
     t_load = time.perf_counter()
     eng = LLMEngine(cfg, ctx, dev)
     note(f"model built in {time.perf_counter() - t_load:.1f} s, {eng.runner.kv_cache_tokens} KV tokens; warming up")
@@ -301,7 +303,7 @@ def main():
     if on_gpu:
         torch.cuda.synchronize()
     t_load = time.perf_counter() - t_load
-    note(f"ready after {t_load:.1f} s ({len(eng.runner.graphs)} decode graphs, self-test {eng.runner.selftest}); replaying")
+    note(f"ready after {t_load:.1f} s ({len(eng.runner.graphs)} graphs, self-test {eng.runner.selftest}); replaying")
 
     def sync_drivers():
         if on_gpu:
@@ -470,12 +472,14 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu,
         "step_tokens": m.step_tokens - before[1],
         "sched_s": m.sched_time - before[2], "exec_s": m.exec_time - before[3], "post_s": m.post_time - before[4],
         "graph_steps": eng.runner.stats["graph_steps"] - before[5]["graph_steps"],
+        "mixed_graph_steps": eng.runner.stats["mixed_graph_steps"] - before[5]["mixed_graph_steps"],
         "eager_steps": eng.runner.stats["eager_steps"] - before[5]["eager_steps"],
         "ar_fallbacks": eng.runner.stats["ar_fallbacks"],
         "running": m.running, "waiting": m.waiting, "kv_used": m.kv_used_frac, "preemptions": m.preemptions,
         "backlog_s": float(time.perf_counter() - t0 - (stamps[rp.nxt - 1] if rp.nxt else 0.0)),
         "arrived": rp.nxt - n_inj_before, "late_queue": len(eng.scheduler.late), "comm": comm_delta,
         "sustained": sus, "replay_seconds": t_end - t0, "steady": steady, "ramp_seconds": t_steady - t0,
+        "sustained_arrivals": int(((stamps > t_end - t0 - sus_s) & (stamps <= t_end - t0)).sum()),
         "ramp_population": rp.population, "ramp_growth": list(growth) if growth else None,
         "capacity_probe": probe, "offered_qps_per_replica": qps,
     }
@@ -554,6 +558,7 @@ def fixed_line(args, allstats, layout, slo, qps, mcfg):
             "sustained_ci95": round(float(1.96 * bins.std(ddof=1) / np.sqrt(len(bins))), 3) if len(bins) > 1 else None,
             "sustained_ttft_p50_s": pct(st, 50), "sustained_ttft_p99_s": pct(st, 99),
             "sustained_tpot_p50_s": pct(sp, 50), "sustained_tpot_p99_s": pct(sp, 99),
+            "sustained_arrivals_per_s": round(sum(s["sustained_arrivals"] for s in allstats) / max(len(bins), 1), 3),
         })
         if line["window_too_short"]:
             # K steps are a second or so of replay: the rate over the steady stretch that ENDS with them is the figure

@@ -118,7 +118,7 @@ def _decode_case(B, ctx, Hq, Hkv, kv_dtype, splits=None):
     return fn, kv_bytes, splits
 
 
-def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0, order="random"):
+def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0, order="random", worklist=None, pages="random"):
     """Serving-shaped batch: log-normal context lengths (the BurstGPT length mix), one decode token each."""
     rng = np.random.default_rng(seed)
     ctx = np.clip(rng.lognormal(np.log(mean_ctx) - 0.32, 0.8, size=B), 8, 2048).astype(np.int64)
@@ -132,7 +132,8 @@ def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0, order="random"):
     kc, vc = allocate_kv_cache(1, nblocks, Hkv, 128, torch.bfloat16, DEV)[0]
     kc.normal_()
     vc.normal_()
-    perm = torch.randperm(nblocks - 1).to(torch.int32)
+    # page placement: scattered over the cache (a block manager after churn) or each sequence's pages in a row
+    perm = (torch.randperm(nblocks - 1) if pages == "random" else torch.arange(nblocks - 1)).to(torch.int32)
     bt = torch.zeros(B, max_nb, dtype=torch.int32)
     o = 0
     for i in range(B):
@@ -145,6 +146,9 @@ def _decode_mixed_case(B, mean_ctx, Hq=32, Hkv=8, seed=0, order="random"):
     splits = ops.choose_decode_splits(B, Hkv, int(ctx.max()))
     ws = torch.empty(B * Hq * splits * 130, dtype=torch.float32, device=DEV)
     meta = ops.AttnMetadata(B, 0, B, None, None, bt, sl, qsl, decode_splits=splits, decode_workspace=ws)
+    if worklist is not None:          # dict(chunk_pages=…, launch_items=…): the per-step work list instead of uniform splits
+        ops.attach_decode_worklist(meta, ctx, Hq, Hkv, DEV, **worklist)
+        splits = f"worklist:{int(meta.counts[0])} items/{meta.decode_items} launched"
     out = torch.empty(B, Hq * 128, device=DEV, dtype=torch.bfloat16)
     fn = lambda: ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, 1 / math.sqrt(128), out=out)
     return fn, int(nb.sum()) * 32 * Hkv * 128 * 2 * 2, splits, float(ctx.mean())
@@ -156,6 +160,17 @@ def bench_decode(quick):
             fn, nbytes, splits, mean = _decode_mixed_case(B, 770, order=order)
             report("paged_attention_decode(mixed lengths)", timeit(fn), bytes_=nbytes, B=B, mean_ctx=round(mean), splits=splits,
                    row_order=order)
+    for B in ([1024] if quick else [256, 1024]):
+        fn, nbytes, splits, mean = _decode_mixed_case(B, 770, order="longest_first", pages="contiguous")
+        report("paged_attention_decode(mixed lengths)", timeit(fn), bytes_=nbytes, B=B, mean_ctx=round(mean), splits=splits,
+               row_order="longest_first", page_placement="contiguous per sequence")
+    # work-list decode: equal-size page ranges instead of one launch-wide split count
+    for B in ([1024] if quick else [64, 256, 1024, 1400]):
+        for order in ("random", "longest_first"):
+            for wl in (dict(), dict(chunk_pages=8), dict(chunk_pages=16), dict(chunk_pages=32), dict(launch_items=3 * B)):
+                fn, nbytes, splits, mean = _decode_mixed_case(B, 770, order=order, worklist=wl)
+                report("paged_attention_decode(mixed lengths, work list)", timeit(fn), bytes_=nbytes, B=B, mean_ctx=round(mean),
+                       splits=splits, row_order=order, **{k: v for k, v in wl.items()})
     cases = [(256, 700), (64, 700), (8, 2048), (1, 2048), (512, 1024)]
     if quick:
         cases = cases[:2]

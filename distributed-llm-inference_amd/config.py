@@ -170,7 +170,11 @@ class EngineConfig:
     use_hip_graphs: bool = True
     # pipelined stepping: queue step N+1 while step N runs (None → on for GPU engines, off on CPU)
     async_scheduling: Optional[bool] = None
-    graph_batch_sizes: tuple = (1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
+    graph_batch_sizes: tuple = (1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024, 1280, 1536,
+                                2048, 3072, 4096)
+    # steps that hold prefill chunks replay captured graphs too (body keyed by the padded token count + LM-head/sampler
+    # graph keyed by the padded number of sampled rows); off: only pure-decode steps are captured
+    mixed_step_graphs: bool = True
     weights_path: Optional[str] = None      # safetensors dir/file; None → random init
     tokenizer_path: Optional[str] = None    # HF tokenizer.json; None → byte-level tokenizer
 

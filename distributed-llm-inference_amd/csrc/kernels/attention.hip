@@ -150,19 +150,40 @@ __device__ __forceinline__ bf16x8 softmax_step(f32x4 (&s)[2], int tok0, int limi
 }
 
 // ==================================================================================================
-// Decode: grid (Hkv, num_seqs, num_splits), 4 waves; wave w takes pages w, w+4, … of its split.  The kv head is the
-// fastest grid index: the 8 heads of a sequence (contiguous 64 KB per page) are read at the same time by neighbouring
-// workgroups, and a long sequence's work is spread over 8 workgroups that start together instead of 8 that start
-// num_seqs ids apart: +3–4 % on mixed-length batches (profiles/kernels_decode_r2aa.txt).
+// Decode: 4 waves per workgroup; wave w takes pages w, w+4, … of the workgroup's page range of one (sequence, kv head).
+// The kv head is the fastest grid index: the 8 heads of a sequence (contiguous 64 KB per page) are read at the same
+// time by neighbouring workgroups, and a long sequence's work is spread over 8 workgroups that start together instead
+// of 8 that start num_seqs ids apart: +3–4 % on mixed-length batches (profiles/kernels_decode_r2aa.txt).
+//
+// Two ways to say which pages a workgroup reads:
+//   WL = true   work list, grid (Hkv, items): `work[item] = {sequence, first page, end page, partial slot}` built by the
+//               host per step (ops.build_decode_work) — page ranges of about equal size whatever the sequence's length,
+//               so a 2048-token row and a 40-token row no longer get the same split count and the tail of the launch is
+//               one chunk long.  slot < 0: the range is the whole sequence, the result goes straight to `out`.  The
+//               number of valid items is read from DEVICE memory (`counts[0]`; extra workgroups exit), which is what
+//               lets a hipGraph with a fixed grid serve any batch.
+//   WL = false  uniform splits, grid (Hkv, num_seqs, num_splits): every sequence is cut into `num_splits` ranges.
+// Partial results: `part_o[(p·Hq + head)·128 + d]`, `part_ml[(p·Hq + head)·2 + {m, l}]` with p = slot (WL) or
+// seq·num_splits + split; decode_reduce_kernel combines them per sequence.
 // ==================================================================================================
-template <bool KV8>
+template <bool KV8, bool WL>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens, uint16_t* __restrict__ out,
     int64_t out_stride, float* __restrict__ part_o, float* __restrict__ part_ml, int Hq, int Hkv, int num_splits,
-    float scale_log2, float v_scale, const float* __restrict__ kv_scales) {
+    float scale_log2, float v_scale, const float* __restrict__ kv_scales, const int4* __restrict__ work,
+    const int* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int seq = blockIdx.y, kvh = blockIdx.x, split = blockIdx.z;
+  const int kvh = blockIdx.x;
+  int seq, b_begin, b_end, part;                           // part < 0: write `out` directly
+  if constexpr (WL) {
+    if ((int)blockIdx.y >= counts[0]) return;
+    const int4 w = work[blockIdx.y];
+    seq = w.x, b_begin = w.y, b_end = w.z, part = w.w;
+  } else {
+    seq = blockIdx.y;
+    part = num_splits == 1 ? -1 : seq * num_splits + (int)blockIdx.z;
+  }
   if (KV8 && kv_scales != nullptr) {                       // calibrated per-(layer, kv head) fp8 scales: [k | v][Hkv]
     scale_log2 *= kv_scales[kvh];
     v_scale = kv_scales[Hkv + kvh];
@@ -172,9 +193,13 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
   const int col = lane & 15, g = lane >> 4;
   const int L = seq_lens[seq];
   const int nblk = (L + 31) >> 5;
-  const int per = (nblk + num_splits - 1) / num_splits;
-  const int b_begin = split * per;
-  const int b_end = min(nblk, b_begin + per);
+  if constexpr (!WL) {
+    const int per = (nblk + num_splits - 1) / num_splits;
+    b_begin = (int)blockIdx.z * per;
+    b_end = min(nblk, b_begin + per);
+  } else {
+    b_end = min(b_end, nblk);
+  }
   constexpr int ESZ = KV8 ? 1 : 2;
 
   bf16x8 qf[4];
@@ -257,32 +282,40 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
       den += f * sm_l[w * G + head];
     }
     const int qh = kvh * G + head;
-    if (num_splits == 1) {
+    if (part < 0) {
       const float r = den > 0.f ? v_scale / den : 0.f;
       out[(int64_t)seq * out_stride + qh * HD + d] = f2bf(num * r);
     } else {
-      const int64_t slot = ((int64_t)seq * Hq + qh) * num_splits + split;
+      const int64_t slot = (int64_t)part * Hq + qh;
       part_o[slot * HD + d] = num;
       if (d == 0) { part_ml[slot * 2] = M; part_ml[slot * 2 + 1] = den; }
     }
   }
 }
 
-// grid (num_seqs, Hq), 128 threads: combine the split partials.
+// Combine the partials of one (sequence, query head): 128 threads, one per d.  Uniform splits: grid (num_seqs, Hq),
+// partials seq·num_splits … ; work list: grid (reduce entries, Hq), `red[i] = {sequence, first partial, count}` and the
+// number of valid entries in `counts[1]` (device memory, like the decode kernel's item count).
 __global__ __launch_bounds__(128) void decode_reduce_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                             uint16_t* __restrict__ out, int64_t out_stride, int Hq,
                                                             int num_splits, float v_scale, const float* __restrict__ kv_scales,
-                                                            int Hkv) {
-  const int seq = blockIdx.x, qh = blockIdx.y, d = threadIdx.x;
+                                                            int Hkv, const int4* __restrict__ red, const int* __restrict__ counts) {
+  int seq = blockIdx.x, first = (int)blockIdx.x * num_splits, n = num_splits;
+  if (red != nullptr) {
+    if ((int)blockIdx.x >= counts[1]) return;
+    const int4 r = red[blockIdx.x];
+    seq = r.x, first = r.y, n = r.z;
+  }
+  const int qh = blockIdx.y, d = threadIdx.x;
   if (kv_scales != nullptr) v_scale = kv_scales[Hkv + qh / (Hq / Hkv)];
-  const int64_t base = ((int64_t)seq * Hq + qh) * num_splits;
   float M = NEG_BIG;
-  for (int s = 0; s < num_splits; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
+  for (int s = 0; s < n; ++s) M = fmaxf(M, part_ml[((int64_t)(first + s) * Hq + qh) * 2]);
   float num = 0.f, den = 0.f;
-  for (int s = 0; s < num_splits; ++s) {
-    const float f = fast_exp2(part_ml[(base + s) * 2] - M);
-    num += f * part_o[(base + s) * HD + d];
-    den += f * part_ml[(base + s) * 2 + 1];
+  for (int s = 0; s < n; ++s) {
+    const int64_t slot = (int64_t)(first + s) * Hq + qh;
+    const float f = fast_exp2(part_ml[slot * 2] - M);
+    num += f * part_o[slot * HD + d];
+    den += f * part_ml[slot * 2 + 1];
   }
   const float r = den > 0.f ? v_scale / den : 0.f;
   out[(int64_t)seq * out_stride + qh * HD + d] = f2bf(num * r);
@@ -350,7 +383,9 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens,
     const int* __restrict__ query_start_loc, const int* __restrict__ tile_seq, const int* __restrict__ tile_q0,
     uint16_t* __restrict__ out, int64_t out_stride, int Hq, int Hkv, int num_tiles, float scale_log2, float v_scale,
-    const float* __restrict__ kv_scales) {
+    const float* __restrict__ kv_scales, const int* __restrict__ counts) {
+  // inside a hipGraph the grid is an upper bound and the step's tile count lives in device memory (counts[2])
+  if (counts != nullptr) num_tiles = counts[2];
   constexpr int ESZ = KV8 ? 1 : 2;
   constexpr int PAGE_BYTES = PAGE_ELEMS * ESZ;
   constexpr int NCH = PAGE_BYTES / (16 * 256);
@@ -548,23 +583,49 @@ void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, c
   const size_t lds = (size_t)(4 * G * (HD + 4) + 8 * G) * sizeof(float);
   dim3 grid(Hkv, num_seqs, num_splits);
   if (kv_fp8)
-    hipLaunchKernelGGL(paged_decode_kernel<true>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
+    hipLaunchKernelGGL((paged_decode_kernel<true, false>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
-                       num_splits, scale_log2, v_scale, kv_scales);
+                       num_splits, scale_log2, v_scale, kv_scales, nullptr, nullptr);
   else
-    hipLaunchKernelGGL(paged_decode_kernel<false>, grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
+    hipLaunchKernelGGL((paged_decode_kernel<false, false>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
-                       num_splits, scale_log2, 1.f, nullptr);
+                       num_splits, scale_log2, 1.f, nullptr, nullptr, nullptr);
   if (num_splits > 1)
     hipLaunchKernelGGL(decode_reduce_kernel, dim3(num_seqs, Hq), dim3(128), 0, stream, part_o, part_ml, (uint16_t*)out,
-                       out_stride, Hq, num_splits, kv_fp8 ? v_scale : 1.f, kv_fp8 ? kv_scales : nullptr, Hkv);
+                       out_stride, Hq, num_splits, kv_fp8 ? v_scale : 1.f, kv_fp8 ? kv_scales : nullptr, Hkv, nullptr, nullptr);
+}
+
+// Work-list decode: `items` / `reds` are the LAUNCHED grid extents (an upper bound inside a hipGraph); the valid counts
+// are counts[0] / counts[1] on the device.
+void launch_paged_decode_worklist(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                  const int* block_tables, int max_blocks, const int* seq_lens, void* out,
+                                  int64_t out_stride, float* part_o, float* part_ml, const int* work, const int* red,
+                                  const int* counts, int items, int reds, int Hq, int Hkv, float scale, bool kv_fp8,
+                                  float k_scale, float v_scale, const float* kv_scales, hipStream_t stream) {
+  if (items <= 0) return;
+  const int G = Hq / Hkv;
+  if (kv_scales != nullptr) k_scale = v_scale = 1.f;
+  const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
+  const size_t lds = (size_t)(4 * G * (HD + 4) + 8 * G) * sizeof(float);
+  dim3 grid(Hkv, items);
+  if (kv_fp8)
+    hipLaunchKernelGGL((paged_decode_kernel<true, true>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
+                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv, 1,
+                       scale_log2, v_scale, kv_scales, (const int4*)work, counts);
+  else
+    hipLaunchKernelGGL((paged_decode_kernel<false, true>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
+                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv, 1,
+                       scale_log2, 1.f, nullptr, (const int4*)work, counts);
+  if (reds > 0)
+    hipLaunchKernelGGL(decode_reduce_kernel, dim3(reds, Hq), dim3(128), 0, stream, part_o, part_ml, (uint16_t*)out,
+                       out_stride, Hq, 1, kv_fp8 ? v_scale : 1.f, kv_fp8 ? kv_scales : nullptr, Hkv, (const int4*)red, counts);
 }
 
 void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                           const int* block_tables, int max_blocks, const int* seq_lens, const int* query_start_loc,
                           const int* tile_seq, const int* tile_q0, int num_tiles, void* out, int64_t out_stride, int Hq,
                           int Hkv, float scale, bool kv_fp8, float k_scale, float v_scale, const float* kv_scales,
-                          hipStream_t stream) {
+                          const int* counts, hipStream_t stream) {
   if (num_tiles == 0) return;
   if (kv_scales != nullptr) k_scale = v_scale = 1.f;
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
@@ -572,11 +633,11 @@ void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, 
   if (kv_fp8)
     hipLaunchKernelGGL(paged_prefill_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
-                       out_stride, Hq, Hkv, num_tiles, scale_log2, v_scale, kv_scales);
+                       out_stride, Hq, Hkv, num_tiles, scale_log2, v_scale, kv_scales, counts);
   else
     hipLaunchKernelGGL(paged_prefill_kernel<false>, grid, dim3(256), 0, stream, (const uint16_t*)q, q_stride, k_cache,
                        v_cache, block_tables, max_blocks, seq_lens, query_start_loc, tile_seq, tile_q0, (uint16_t*)out,
-                       out_stride, Hq, Hkv, num_tiles, scale_log2, 1.f, nullptr);
+                       out_stride, Hq, Hkv, num_tiles, scale_log2, 1.f, nullptr, counts);
 }
 
 }  // namespace dli

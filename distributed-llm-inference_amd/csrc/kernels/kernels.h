@@ -21,11 +21,16 @@ void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, c
                          const int* block_tables, int max_blocks, const int* seq_lens, void* out, int64_t out_stride,
                          float* part_o, float* part_ml, int num_seqs, int Hq, int Hkv, int num_splits, float scale,
                          bool kv_fp8, float k_scale, float v_scale, const float* kv_scales, hipStream_t stream);
+void launch_paged_decode_worklist(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                                  const int* block_tables, int max_blocks, const int* seq_lens, void* out,
+                                  int64_t out_stride, float* part_o, float* part_ml, const int* work, const int* red,
+                                  const int* counts, int items, int reds, int Hq, int Hkv, float scale, bool kv_fp8,
+                                  float k_scale, float v_scale, const float* kv_scales, hipStream_t stream);
 void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                           const int* block_tables, int max_blocks, const int* seq_lens, const int* query_start_loc,
                           const int* tile_seq, const int* tile_q0, int num_tiles, void* out, int64_t out_stride, int Hq,
                           int Hkv, float scale, bool kv_fp8, float k_scale, float v_scale, const float* kv_scales,
-                          hipStream_t stream);
+                          const int* counts, hipStream_t stream);
 
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
                           int M, int N, int K, bool swiglu, hipStream_t stream);

@@ -154,10 +154,42 @@ void paged_attention_decode(Tensor out, const Tensor& q, const Tensor& k_cache, 
                            (float)v_scale, scales_ptr(kv_scales, Hkv), cur_stream(q));
 }
 
+// Work-list decode (ops.build_decode_work): `work` int32 [≥ items, 4] = {sequence, first page, end page, partial slot},
+// `red` int32 [≥ reds, 4] = {sequence, first partial, partials, 0}, `counts` int32 [≥ 4] ON THE DEVICE = {valid items,
+// valid reduce entries, prefill tiles, -}.  `items` / `reds` are the launched grid extents (≥ the valid counts).
+void paged_attention_decode_worklist(Tensor out, const Tensor& q, const Tensor& k_cache, const Tensor& v_cache,
+                                     const Tensor& block_tables, const Tensor& seq_lens, const Tensor& work, const Tensor& red,
+                                     const Tensor& counts, int64_t items, int64_t reds, int64_t max_parts, int64_t Hq, int64_t Hkv,
+                                     double scale, const Tensor& workspace, double k_scale, double v_scale,
+                                     const c10::optional<Tensor>& kv_scales) {
+  check_bf16_rows(q, "q");
+  check_bf16_rows(out, "out");
+  check_i32(block_tables, "block_tables");
+  check_i32(seq_lens, "seq_lens");
+  check_i32(work, "work");
+  check_i32(red, "red");
+  check_i32(counts, "counts");
+  check_cache(k_cache, v_cache, Hkv);
+  TORCH_CHECK(Hq % Hkv == 0 && Hq / Hkv <= 16, "decode kernel supports up to 16 query heads per KV head");
+  TORCH_CHECK(q.size(1) == Hq * 128 && out.size(1) == Hq * 128 && block_tables.dim() == 2);
+  TORCH_CHECK(items >= 0 && items <= 65535 && reds >= 0 && reds <= 65535 && work.numel() >= 4 * items && red.numel() >= 4 * reds &&
+              counts.numel() >= 4, "work list / reduce list shorter than the launched grid");
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(work.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(red.data_ptr()) % 16 == 0);
+  TORCH_CHECK(workspace.is_cuda() && workspace.scalar_type() == at::kFloat && workspace.is_contiguous());
+  TORCH_CHECK(workspace.numel() >= max_parts * Hq * (128 + 2), "decode workspace too small for ", max_parts, " partials");
+  float* part_o = workspace.data_ptr<float>();
+  float* part_ml = part_o + max_parts * Hq * 128;
+  dli::launch_paged_decode_worklist(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr<int>(),
+                                    (int)block_tables.size(1), seq_lens.data_ptr<int>(), out.data_ptr(), out.stride(0), part_o,
+                                    part_ml, work.data_ptr<int>(), red.data_ptr<int>(), counts.data_ptr<int>(), (int)items,
+                                    (int)reds, (int)Hq, (int)Hkv, (float)scale, is_fp8(k_cache), (float)k_scale, (float)v_scale,
+                                    scales_ptr(kv_scales, Hkv), cur_stream(q));
+}
+
 void paged_attention_prefill(Tensor out, const Tensor& q, const Tensor& k_cache, const Tensor& v_cache, const Tensor& block_tables,
                              const Tensor& seq_lens, const Tensor& query_start_loc, const Tensor& tile_seq, const Tensor& tile_q0,
                              int64_t num_tiles, int64_t Hq, int64_t Hkv, double scale, double k_scale, double v_scale,
-                             const c10::optional<Tensor>& kv_scales) {
+                             const c10::optional<Tensor>& kv_scales, const c10::optional<Tensor>& counts) {
   check_bf16_rows(q, "q");
   check_bf16_rows(out, "out");
   check_i32(block_tables, "block_tables");
@@ -170,11 +202,17 @@ void paged_attention_prefill(Tensor out, const Tensor& q, const Tensor& k_cache,
   TORCH_CHECK(Hq % Hkv == 0 && (G == 1 || G == 2 || G == 4 || G == 8), "prefill kernel supports 1, 2, 4 or 8 query heads per KV head");
   TORCH_CHECK(q.size(1) == Hq * 128 && out.size(1) == Hq * 128 && out.size(0) == q.size(0));
   TORCH_CHECK(tile_seq.numel() >= num_tiles && tile_q0.numel() >= num_tiles && block_tables.dim() == 2);
+  const int* cnt = nullptr;                 // device-side tile count (counts[2]); num_tiles is then the grid's upper bound
+  if (counts.has_value()) {
+    check_i32(*counts, "counts");
+    TORCH_CHECK(counts->numel() >= 4);
+    cnt = counts->data_ptr<int>();
+  }
   dli::launch_paged_prefill(q.data_ptr(), q.stride(0), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr<int>(),
                             (int)block_tables.size(1), seq_lens.data_ptr<int>(), query_start_loc.data_ptr<int>(),
                             tile_seq.data_ptr<int>(), tile_q0.data_ptr<int>(), (int)num_tiles, out.data_ptr(), out.stride(0),
                             (int)Hq, (int)Hkv, (float)scale, is_fp8(k_cache), (float)k_scale, (float)v_scale,
-                            scales_ptr(kv_scales, Hkv), cur_stream(q));
+                            scales_ptr(kv_scales, Hkv), cnt, cur_stream(q));
 }
 
 void sample(Tensor out, const Tensor& logits, const Tensor& temperature, const Tensor& top_p, const Tensor& top_k,
@@ -418,7 +456,10 @@ TORCH_LIBRARY(dli, m) {
         "float v_scale, Tensor? kv_scales=None) -> ()", &paged_attention_decode);
   m.def("paged_attention_prefill(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, Tensor seq_lens, "
         "Tensor query_start_loc, Tensor tile_seq, Tensor tile_q0, int num_tiles, int num_heads, int num_kv_heads, float scale, "
-        "float k_scale, float v_scale, Tensor? kv_scales=None) -> ()", &paged_attention_prefill);
+        "float k_scale, float v_scale, Tensor? kv_scales=None, Tensor? counts=None) -> ()", &paged_attention_prefill);
+  m.def("paged_attention_decode_worklist(Tensor(a!) out, Tensor q, Tensor k_cache, Tensor v_cache, Tensor block_tables, "
+        "Tensor seq_lens, Tensor work, Tensor red, Tensor counts, int items, int reds, int max_parts, int Hq, int Hkv, float scale, "
+        "Tensor workspace, float k_scale, float v_scale, Tensor? kv_scales=None) -> ()", &paged_attention_decode_worklist);
   m.def("gather_sampled(Tensor(a!) input, Tensor src, Tensor sampled) -> ()", &gather_sampled);
   m.def("sample(Tensor(a!) out, Tensor logits, Tensor temperature, Tensor top_p, Tensor top_k, Tensor seeds, Tensor steps, "
         "Tensor? noise) -> ()", &sample);

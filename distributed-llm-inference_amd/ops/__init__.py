@@ -59,8 +59,17 @@ class AttnMetadata:
     seq_lens: torch.Tensor             # [B] int32, context length *including* this step's tokens
     query_start_loc: torch.Tensor      # [B+1] int32
     max_seq_len: int = 0
-    decode_splits: int = 1
+    decode_splits: int = 1             # uniform-split decode (no work list): launch-wide split count
     decode_workspace: Optional[torch.Tensor] = None
+    # work-list decode (build_decode_work): device views of the step buffer + the LAUNCHED grid extents (exact for an
+    # eager step, the capture-time upper bounds inside a hipGraph; the valid counts are counts[0:2] on the device)
+    decode_work: Optional[torch.Tensor] = None      # int32 [items_cap, 4]
+    decode_red: Optional[torch.Tensor] = None       # int32 [reds_cap, 4]
+    counts: Optional[torch.Tensor] = None           # int32 [4]: decode items, reduce entries, prefill tiles, -
+    decode_items: int = 0
+    decode_reds: int = 0
+    decode_max_parts: int = 0
+    counts_on_device: bool = False     # hipGraph step: kernels take the prefill tile count from counts[2] as well
     # prefill work list: one entry per TQ-token tile
     prefill_tile_seq: Optional[torch.Tensor] = None
     prefill_tile_q0: Optional[torch.Tensor] = None
@@ -102,6 +111,88 @@ def choose_decode_splits(num_seqs: int, num_kv_heads: int, max_seq_len: int, num
     pages = max((max_seq_len + 31) // 32, 1)
     want = (2 * num_cus + groups - 1) // groups          # aim for ≥ 2 workgroups per CU
     return int(max(1, min(want, (pages + 3) // 4, 16)))   # keep ≥ 4 pages (one per wave) per split
+
+
+def decode_chunk_pages(seq_lens: np.ndarray, num_kv_heads: int, cap_items: int = 0, num_cus: int = 256) -> int:
+    """Pages per work item of the decode kernel.  Measured (``profiles/kernels_decode_r3b.txt``): once (rows × kv heads)
+    alone fill the chip with ≥ 2 workgroups per CU, cutting rows further only LOSES bandwidth (B = 1024: whole rows
+    5.73 TB/s, 32-page ranges 5.64, 16-page 5.40, 8-page 5.11 — per-workgroup fixed cost and the extra reduce pass
+    outweigh the better balance; row order, longest first, is what recovers the tail), so big batches get ONE range per
+    row.  Smaller batches cut the longest row into as many ranges as it takes to reach that fill (whole multiples of 4
+    pages: one per wave and iteration) — each row by its own length, a short row stays one range.  ``cap_items``:
+    ranges are doubled until the list fits (the fixed grid of a hipGraph)."""
+    pages = (np.asarray(seq_lens, dtype=np.int64) + 31) >> 5
+    n, maxp = len(pages), max(int(pages.max()) if len(pages) else 1, 1)
+    want = (2 * num_cus + n * num_kv_heads - 1) // max(n * num_kv_heads, 1)      # ranges the longest row should give
+    if want <= 1:
+        return (maxp + 3) // 4 * 4
+    c = (max((maxp + want - 1) // want, 4) + 3) // 4 * 4
+    if cap_items:
+        while int(((pages + c - 1) // c).sum()) > cap_items and c < maxp:
+            c *= 2
+    return c
+
+
+def decode_launch_caps(rows: int, num_kv_heads: int, num_cus: int = 256):
+    """Upper bounds ``(work items, reduce entries)`` of a decode launch over at most ``rows`` rows — the grid a hipGraph
+    captures.  Rows are only ever cut while (rows × kv heads) < 2 workgroups per CU, and then into about that many
+    ranges in total, so the list never exceeds ``rows + 2·CUs / kv heads`` and at most ``2·CUs / kv heads`` rows are cut."""
+    fill = 2 * num_cus // max(num_kv_heads, 1)
+    return rows + fill, min(rows, fill)
+
+
+def build_decode_work(seq_lens: np.ndarray, num_kv_heads: int, cap_items: int = 0, chunk_pages: int = 0):
+    """Host-side work list of the decode kernel (no launch-wide split count).
+
+    Every sequence's pages are cut into ``ceil(pages / chunk)`` ranges of EQUAL size (rounded up to 4 pages), so a
+    2048-token row becomes several workgroups per kv head and a 40-token row one.  Returns
+    ``work int32 [items, 4] = (row, first page, end page, partial slot | -1)``, ``red int32 [r, 4] = (row, first
+    partial, partials, 0)`` for the rows with more than one range, and the number of partial slots."""
+    L = np.asarray(seq_lens, dtype=np.int64)
+    n = len(L)
+    if n == 0:
+        return np.zeros((0, 4), np.int32), np.zeros((0, 4), np.int32), 0
+    pages = np.maximum((L + 31) >> 5, 1)
+    c = chunk_pages or decode_chunk_pages(L, num_kv_heads, cap_items)
+    k = (pages + c - 1) // c                                   # ranges per row
+    per = ((pages + k - 1) // k + 3) // 4 * 4                  # equal-size ranges, whole wave rounds
+    k = (pages + per - 1) // per
+    total = int(k.sum())
+    row = np.repeat(np.arange(n), k)
+    first = np.cumsum(k) - k
+    j = np.arange(total) - first[row]
+    begin = j * per[row]
+    end = np.minimum(begin + per[row], pages[row])
+    multi = k > 1
+    pk = np.where(multi, k, 0)
+    pfirst = np.cumsum(pk) - pk
+    slot = np.where(multi[row], pfirst[row] + j, -1)
+    work = np.stack([row, begin, end, slot], axis=1).astype(np.int32)
+    mrows = np.flatnonzero(multi)
+    red = np.stack([mrows, pfirst[mrows], k[mrows], np.zeros_like(mrows)], axis=1).astype(np.int32)
+    return work, red, int(pk.sum())
+
+
+def attach_decode_worklist(meta: AttnMetadata, seq_lens: np.ndarray, num_heads: int, num_kv_heads: int, device,
+                           cap_items: int = 0, chunk_pages: int = 0, launch_items: int = 0) -> AttnMetadata:
+    """Tests / benchmarks: build the decode work list of ``seq_lens`` (host copy of the first ``meta.num_decode`` rows)
+    and hang it — device tensors, workspace, counts — on ``meta``.  ``launch_items`` > 0 launches that many workgroups
+    per kv head instead of the exact count (what a hipGraph does); the kernel takes the valid count from ``counts``."""
+    work, red, n_parts = build_decode_work(seq_lens, num_kv_heads, cap_items, chunk_pages)
+    n_items, n_reds = len(work), len(red)
+    li = max(launch_items, n_items)
+    lr = max(launch_items, n_reds) if launch_items else n_reds
+    w = np.zeros((li + 1, 4), np.int32)
+    w[:n_items] = work
+    r = np.zeros((lr + 1, 4), np.int32)
+    r[:n_reds] = red
+    meta.decode_work = torch.from_numpy(w).to(device)
+    meta.decode_red = torch.from_numpy(r).to(device)
+    meta.counts = torch.tensor([n_items, n_reds, meta.num_prefill_tiles, 0], dtype=torch.int32, device=device)
+    meta.decode_items, meta.decode_reds = li, lr
+    meta.decode_max_parts = max(li, 1)
+    meta.decode_workspace = torch.empty(meta.decode_max_parts * num_heads * 130, dtype=torch.float32, device=device)
+    return meta
 
 
 # ------------------------------------------------------------------------------------ ops
@@ -215,14 +306,20 @@ def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
         if out is None:
             out = torch.empty(T, num_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
         lib = hip()
-        if meta.num_decode > 0:
+        if meta.decode_items > 0:
+            lib.paged_attention_decode_worklist(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
+                                                meta.decode_work, meta.decode_red, meta.counts, meta.decode_items,
+                                                meta.decode_reds, meta.decode_max_parts, num_heads, num_kv_heads, scale,
+                                                meta.decode_workspace, k_scale, v_scale, kv_scales)
+        elif meta.num_decode > 0 and meta.decode_work is None:
             lib.paged_attention_decode(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens, meta.num_decode,
                                        num_heads, num_kv_heads, scale, meta.decode_splits, meta.decode_workspace,
                                        k_scale, v_scale, kv_scales)
         if meta.num_prefill_tiles > 0:
             lib.paged_attention_prefill(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
                                         meta.query_start_loc, meta.prefill_tile_seq, meta.prefill_tile_q0,
-                                        meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale, kv_scales)
+                                        meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale, kv_scales,
+                                        meta.counts if meta.counts_on_device else None)
         return out
     B = meta.num_decode + meta.num_prefill
     if kv_scales is not None:

@@ -7,9 +7,13 @@ copies → kernels (or one graph launch) → one D2H of the sampled ids.  All ke
 metadata from *static* device buffers, which is what makes the decode step capturable: a replay only
 needs the buffers refreshed, never new launch arguments.
 
-hipGraph buckets: one graph per padded batch size; padding rows have ``seq_len = 0`` and
-``slot = -1`` so the kernels skip them.  The KV-split count of the decode kernel is a launch
-dimension, hence fixed per bucket at capture time (small buckets → more splits).
+hipGraphs.  *Decode* graphs: one per padded batch size (forward + LM head + sampler); padding rows have
+``slot = -1`` and belong to no work item, so the kernels skip them.  *Mixed* graphs: a step that
+holds prefill chunks replays a *body* graph keyed by its token count rounded up to a bucket (the scheduler already
+aligns large steps to 256 tokens) followed by a *head* graph (LM head + sampler) keyed by the padded number of
+sampled rows.  What makes one captured launch sequence serve any batch composition: every attention kernel takes its
+work from lists in the static step buffer — decode page ranges (``ops.build_decode_work``), prefill tiles — with the
+VALID counts in device memory (``counts``); grids are launched at the bucket's upper bound and surplus workgroups exit.
 """
 from __future__ import annotations
 
@@ -74,7 +78,7 @@ class ModelRunner:
         self.graphs: dict[int, tuple] = {}
         self.graph_pool = None
         self.tile_tokens = ops.prefill_tile_tokens(self.local_heads, self.local_kv_heads)
-        self.stats = {"graph_steps": 0, "eager_steps": 0, "ar_fallbacks": 0}
+        self.stats = {"graph_steps": 0, "mixed_graph_steps": 0, "eager_steps": 0, "ar_fallbacks": 0}
         self.selftest: dict = {}                             # start-up checks of the fast paths → what got disabled
         self._dumped = False
         self._ar_vote = 0                                    # this rank saw its all-reduce kernel time out
@@ -116,9 +120,11 @@ class ModelRunner:
         T, B = s.max_num_batched_tokens, s.max_num_seqs
         self.max_T, self.max_B = T, B
         max_tiles = T // 16 + B + 1
+        self.items_cap = min(ops.decode_launch_caps(B, self.local_kv_heads)[0], 65535)   # decode work items of one step
         fields = [("input", T), ("pos", T), ("slot", T), ("seq_lens", B), ("qsl", B + 1), ("last", B),
                   ("top_k", B), ("temp", B), ("top_p", B), ("seeds", 2 * B), ("steps", 2 * B),
                   ("src", B), ("tile_seq", max_tiles), ("tile_q0", max_tiles), ("cow", 2 * self.MAX_COW),
+                  ("counts", 4), ("dwork", 4 * self.items_cap), ("dred", 4 * B),
                   ("bt", B * self.max_blocks_per_seq)]
         self.layout, off = {}, 0
         for name, n in fields:
@@ -135,6 +141,7 @@ class ModelRunner:
             v["temp"], v["top_p"] = v["temp"].view(torch.float32), v["top_p"].view(torch.float32)
             v["seeds"], v["steps"] = v["seeds"].view(torch.int64), v["steps"].view(torch.int64)
             v["bt"] = v["bt"].view(B, self.max_blocks_per_seq)
+            v["dwork"], v["dred"] = v["dwork"].view(-1, 4), v["dred"].view(-1, 4)
             return v
 
         self.dv = views(self.d_buf)
@@ -148,9 +155,11 @@ class ModelRunner:
         self.h_sampled = [_pinned(B, torch.int64, self.on_gpu) for _ in range(2)]
         self._fetch_idx = 0
         self._prev_event = None
-        max_splits = 16
-        self.decode_ws = (torch.empty(B * self.local_heads * max_splits * 130, dtype=torch.float32, device=self.device)
+        # partial results of the decode kernel: one slot per work item at most
+        self.decode_ws = (torch.empty(self.items_cap * self.local_heads * 130, dtype=torch.float32, device=self.device)
                           if self.on_gpu else None)
+        # hidden states of the sampled rows: written by a mixed step's body graph, read by its head graph
+        self.h_last = torch.zeros(B, self.cfg.model.hidden_size, dtype=self.dtype, device=self.device) if self.on_gpu else None
 
     def _bind_host(self, i: int):
         self._host_idx = i
@@ -160,7 +169,7 @@ class ModelRunner:
         self.n_bt, self.n_seq_lens, self.n_qsl = nv["bt"], nv["seq_lens"], nv["qsl"]
 
     # ------------------------------------------------------------------ batch → device
-    def _stage(self, batch, bm, cow=()):
+    def _stage(self, batch, bm, cow=(), cap_items: int = 0):
         reqs = batch.requests
         if len(cow) > self.MAX_COW:
             raise RuntimeError(f"{len(cow)} copy-on-write pages in one step (limit {self.MAX_COW})")
@@ -200,27 +209,41 @@ class ModelRunner:
             n_tiles = len(ts)
             nv["tile_seq"][:n_tiles] = ts
             nv["tile_q0"][:n_tiles] = t0
-        return B, T, S, n_tiles, n_src
+        n_items, n_reds, n_parts = self._stage_decode_work(nd, cap_items)
+        nv["counts"][:4] = (n_items, n_reds, n_tiles, 0)
+        return B, T, S, n_tiles, n_src, n_items, n_reds, n_parts
+
+    def _stage_decode_work(self, nd: int, cap_items: int = 0):
+        """Work list of the decode kernel for rows ``0 … nd-1`` of the staged batch (GPU only: the CPU reference
+        attention walks the block tables itself)."""
+        if not (nd and self.on_gpu):
+            return 0, 0, 0
+        work, red, n_parts = ops.build_decode_work(self.n_seq_lens[:nd], self.local_kv_heads,
+                                                   min(cap_items or self.items_cap, self.items_cap))
+        self.nv["dwork"][:len(work)] = work
+        self.nv["dred"][:len(red)] = red
+        return len(work), len(red), n_parts
 
     def _copy_in(self):
         self.d_buf.copy_(self.h_buf, non_blocking=True)
 
-    def _meta(self, B, T, num_decode, max_seq_len, splits, n_tiles) -> AttnMetadata:
+    def _meta(self, B, T, num_decode, n_items, n_reds, n_tiles, counts_on_device: bool = False) -> AttnMetadata:
+        """``n_items`` / ``n_reds`` / ``n_tiles`` are the LAUNCHED extents: the step's own counts for an eager step, a
+        bucket's upper bounds (``counts_on_device``) inside a hipGraph."""
         dv = self.dv
         return AttnMetadata(num_decode=num_decode, num_prefill=B - num_decode, num_tokens=T,
                             positions=dv["pos"][:T], slot_mapping=dv["slot"][:T], block_tables=dv["bt"],
-                            seq_lens=dv["seq_lens"], query_start_loc=dv["qsl"], max_seq_len=max_seq_len,
-                            decode_splits=splits, decode_workspace=self.decode_ws,
+                            seq_lens=dv["seq_lens"], query_start_loc=dv["qsl"], max_seq_len=0,
+                            decode_workspace=self.decode_ws, decode_work=dv["dwork"], decode_red=dv["dred"],
+                            counts=dv["counts"], decode_items=n_items, decode_reds=n_reds, decode_max_parts=self.items_cap,
+                            counts_on_device=counts_on_device,
                             prefill_tile_seq=dv["tile_seq"], prefill_tile_q0=dv["tile_q0"],
                             num_prefill_tiles=n_tiles)
 
     # ------------------------------------------------------------------ forward + sample
-    def _forward_sample(self, T, S, meta):
+    def _sample_rows(self, h_rows, S):
         dv = self.dv
-        h = self.model(dv["input"][:T], meta, self.kv_caches)
-        if S == 0:
-            return None
-        logits = self.model.compute_logits(h.index_select(0, dv["last"][:S]))
+        logits = self.model.compute_logits(h_rows)
         if _DUMP_LOGITS and self.ctx.is_driver and not torch.cuda.is_current_stream_capturing() and not self._dumped:
             self._dumped = True                              # debug aid: first sampled row of the first eager step
             torch.save(logits[0].float().cpu(), _DUMP_LOGITS)
@@ -231,21 +254,76 @@ class ModelRunner:
                    out=self.d_sampled[:S])
         return logits
 
+    def _forward_sample(self, T, S, meta):
+        dv = self.dv
+        h = self.model(dv["input"][:T], meta, self.kv_caches)
+        if S == 0:
+            return None
+        return self._sample_rows(h.index_select(0, dv["last"][:S]), S)
+
+    # ------------------------------------------------------------------ step planning
+    def _plan(self, B: int, T: int, nd: int, S: int):
+        """Which captured graphs (if any) serve a step of B sequences / T tokens / nd decode rows / S sampled rows:
+        ``(decode bucket, mixed token bucket, head bucket)`` — all 0 for an eager step."""
+        if not (self.on_gpu and self.cfg.use_hip_graphs):
+            return 0, 0, 0
+        if nd == B and S == B:
+            return self._bucket_for(B) or 0, 0, 0
+        if not self.cfg.mixed_step_graphs:
+            return 0, 0, 0
+        tb = self._mixed_bucket(T)
+        sb = (self._bucket_for(S) or 0) if S else 0
+        if not tb or (S and not sb) or B > min(tb, self.max_B):
+            return 0, 0, 0
+        return 0, tb, sb
+
+    def _mixed_bucket(self, T: int) -> int:
+        for b in self.mixed_buckets:
+            if b >= T:
+                return b
+        return 0
+
+    @property
+    def mixed_buckets(self) -> tuple:
+        """Token counts a mixed step is padded to: small powers of two, then every 256 (the scheduler's alignment)."""
+        if not hasattr(self, "_mixed_buckets"):
+            top = self.max_T
+            bs = [b for b in (32, 64, 128) if b < top] + list(range(256, top + 1, 256))
+            if top not in bs:
+                bs.append(top)
+            self._mixed_buckets = tuple(sorted(set(bs)))
+        return self._mixed_buckets
+
+    def _decode_caps(self, bucket: int):
+        """(work items, reduce entries) a decode graph of ``bucket`` rows launches.  Where even the smallest batch this
+        bucket serves (one more row than the next smaller bucket) fills the chip, no row is ever cut
+        (``ops.decode_chunk_pages``) and the graph holds one workgroup per (row, kv head) and no reduce pass."""
+        items, reds = ops.decode_launch_caps(bucket, self.local_kv_heads)
+        smaller = [b for b in self.cfg.graph_batch_sizes if b < bucket]
+        fewest_rows = (max(smaller) if smaller else 0) + 1   # the smallest batch that lands in this bucket
+        if fewest_rows * self.local_kv_heads >= 512:
+            return bucket, 0
+        return min(items, self.items_cap), reds
+
+    def _mixed_caps(self, tb: int):
+        """Launch extents of a mixed graph of ``tb`` tokens: decode rows / work items / reduce entries / prefill tiles."""
+        rows = min(tb, self.max_B)
+        items, reds = ops.decode_launch_caps(rows, self.local_kv_heads)
+        return rows, min(items, self.items_cap), reds, tb // self.tile_tokens + min(rows, 256)
+
     @torch.inference_mode()
     def launch(self, batch, bm, cow=()):
         """Driver-side first half of a step: stage the batch, (broadcast it to the TP workers,) queue the
         forward pass, the sampler and the D2H copy of the sampled ids.  Returns a handle for ``collect``.
         At most one earlier step may still be uncollected (its sampled ids are then read on the device)."""
         self._bind_host(self._host_idx ^ 1)
-        B, T, S, n_tiles, n_src = self._stage(batch, bm, cow)
         nd = batch.num_decode
-        bucket = 0
-        if nd == B and S == B and self.on_gpu and self.cfg.use_hip_graphs:
-            bucket = self._bucket_for(B) or 0
-        splits = 1
-        if self.on_gpu and nd and not bucket:
-            splits = ops.choose_decode_splits(nd, self.local_kv_heads, int(self.n_seq_lens[:nd].max()))
-        header = (B, T, S, nd, n_tiles, bucket, splits, n_src, len(cow))
+        bucket, tb, sb = self._plan(len(batch.requests), batch.total_tokens, nd, int(batch.sample_mask.sum()))
+        cap = self._decode_caps(bucket)[0] if bucket else (self._mixed_caps(tb)[1] if tb else 0)
+        B, T, S, n_tiles, n_src, n_items, n_reds, _ = self._stage(batch, bm, cow, cap)
+        if tb and n_tiles > self._mixed_caps(tb)[3]:
+            tb = sb = 0                                      # more prefill sequences than the graph's tile grid: eager
+        header = (B, T, S, nd, n_tiles, bucket, n_items, n_src, len(cow), n_reds, tb, sb)
         if self.ctx.tp_size > 1:
             self._broadcast_step(header)
         return self.run_staged(header)
@@ -275,30 +353,33 @@ class ModelRunner:
     def execute(self, batch, bm) -> np.ndarray:
         return self.collect(self.launch(batch, bm))
 
+    HEADER_FIELDS = 12
+
     def _broadcast_step(self, header):
         """Driver → workers: the step header over the CPU (gloo) group, the packed step buffer over the device
         path (the IPC broadcast kernel when the custom collectives are up, else the device group's broadcast).
 
-        The header travels as a SUM all-reduce of 10 int64: the driver contributes the 9 header fields, every rank
+        The header travels as a SUM all-reduce of 13 int64: the driver contributes the 12 header fields, every rank
         contributes its "my all-reduce kernel timed out" vote in the last slot — so a time-out seen by ANY rank
         reaches all of them with the next step, and the whole group leaves the custom kernels at the same step."""
         import torch.distributed as dist
         ctx = self.ctx
-        hdr = torch.zeros(10, dtype=torch.int64)
+        n = self.HEADER_FIELDS
+        hdr = torch.zeros(n + 1, dtype=torch.int64)
         if ctx.is_driver:
-            hdr[:9] = torch.tensor(header, dtype=torch.int64)
-        hdr[9] = self._ar_vote
+            hdr[:n] = torch.tensor(header, dtype=torch.int64)
+        hdr[n] = self._ar_vote
         g = ctx.cpu_group if ctx.cpu_group is not None else ctx.group
         dist.all_reduce(hdr, group=g)
         if int(hdr[0]) < 0:
             return None
-        if int(hdr[9]) > 0 and ctx.custom_ar is not None and ctx.custom_ar.enabled:
+        if int(hdr[n]) > 0 and ctx.custom_ar is not None and ctx.custom_ar.enabled:
             ctx.disable_custom_ar("a rank's kernel gave up waiting for a peer")
             self.graphs.clear()                              # they hold the custom kernels
             self.stats["ar_fallbacks"] += 1
             if dist.get_backend(ctx.group) != "nccl":
                 self.cfg.use_hip_graphs = False              # host-staged collectives cannot be captured
-        head = tuple(int(x) for x in hdr[:9])
+        head = tuple(int(x) for x in hdr[:n])
         if ctx.is_driver:
             self._pad_for(head)
             self._copy_in()
@@ -322,25 +403,26 @@ class ModelRunner:
         if self.ctx.tp_size > 1 and self.ctx.is_driver:
             import torch.distributed as dist
             g = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
-            hdr = torch.zeros(10, dtype=torch.int64)
+            hdr = torch.zeros(self.HEADER_FIELDS + 1, dtype=torch.int64)
             hdr[0] = -1
             dist.all_reduce(hdr, group=g)
 
     def _pad_for(self, header):
-        B, bucket = header[0], header[5]
+        B, T, S, bucket, tb, sb = header[0], header[1], header[2], header[5], header[10], header[11]
         if bucket:
             self._pad_decode(B, bucket)
+        elif tb:
+            self._pad_mixed(T, S, tb, sb)
 
     @torch.inference_mode()
     def run_staged(self, header, staged_on_device: bool = False):
-        B, T, S, nd, n_tiles, bucket, splits, n_src, n_cow = header
+        B, T, S, nd, n_tiles, bucket, n_items, n_src, n_cow, n_reds, tb, sb = header
         tp_staged = self.ctx.tp_size > 1                    # _broadcast_step already padded + copied
-        if bucket and not tp_staged:
-            self._pad_decode(B, bucket)
         if not tp_staged:
+            self._pad_for(header)
             self._copy_in()
         if _DEBUG_BOUNDS:
-            self._check_bounds(B if not bucket else bucket, T if not bucket else bucket, n_cow)
+            self._check_bounds(B, T, n_cow)
         if n_cow:
             # n > 1 forks: give the children private copies of the page they are about to write (every layer's K and V;
             # stream-ordered behind the step that filled the source pages, ahead of this step's kernels)
@@ -352,26 +434,42 @@ class ModelRunner:
             # decode rows whose input id was sampled by the step still in flight: take it from the sampler's
             # device output (stream order puts this behind that step and ahead of this step's sampler)
             ops.gather_sampled(self.dv["input"][:nd], self.dv["src"][:nd], self.d_sampled)
-        if bucket and not self.cfg.use_hip_graphs:
-            # the bucket was chosen before graphs were switched off (all-reduce fallback in this very step): run the
-            # padded batch eagerly — padding rows are inert, the split count is the bucket's on every rank
-            B_pad, splits = bucket, self._splits_for_bucket(bucket)
-            self._forward_sample(B_pad, B_pad, self._meta(B_pad, B_pad, B_pad, 0, splits, 0))
+        if (bucket or tb) and not self.cfg.use_hip_graphs:
+            # the graphs were chosen before they were switched off (all-reduce fallback in this very step): run the
+            # padded batch eagerly — padding rows are inert, the work lists are exact on every rank
+            if bucket:
+                self._forward_sample(bucket, bucket, self._meta(bucket, bucket, bucket, n_items, n_reds, 0))
+            else:
+                self._forward_sample(tb, S, self._meta(B, tb, nd, n_items, n_reds, n_tiles))
             self.stats["eager_steps"] += 1
-            return self._fetch(B)
+            return self._fetch(B if bucket else S)
         if bucket:
             if bucket not in self.graphs:
                 self.capture_graph(bucket)
-            g = self.graphs[bucket]
-            g[0].replay()
-            for k, v in g[3].items():                        # collectives inside the graph, counted at capture
-                self.ctx.comm[k] += v
+            self._replay(bucket)
             self.stats["graph_steps"] += 1
             return self._fetch(B)
-        meta = self._meta(B, T, nd, 0, splits, n_tiles)
+        if tb:
+            if ("m", tb) not in self.graphs:
+                self.capture_mixed_graph(tb)
+            self._replay(("m", tb))
+            if S:
+                if ("h", sb) not in self.graphs:
+                    self.capture_head_graph(sb)
+                self._replay(("h", sb))
+            self.stats["graph_steps"] += 1
+            self.stats["mixed_graph_steps"] += 1
+            return self._fetch(S)
+        meta = self._meta(B, T, nd, n_items, n_reds, n_tiles)
         self._forward_sample(T, S, meta)
         self.stats["eager_steps"] += 1
         return self._fetch(S)
+
+    def _replay(self, key):
+        g = self.graphs[key]
+        g[0].replay()
+        for k, v in g[3].items():                            # collectives inside the graph, counted at capture
+            self.ctx.comm[k] += v
 
     def _check_bounds(self, B: int, T: int, n_cow: int) -> None:
         """``DLI_DEBUG_BOUNDS=1``: before any kernel of the step runs, read the step's metadata back
@@ -389,6 +487,21 @@ class ModelRunner:
             row = bt[i, :used]
             assert row.size == 0 or (row.min() >= 0 and row.max() < nb), f"block table row {i}: {row.min()}..{row.max()} / {nb}"
         assert ids.size == 0 or ids.max() < self.cfg.model.vocab_size, f"token id {ids.max()} >= vocab"
+        counts = dv["counts"].cpu().numpy()
+        n_items, n_reds = int(counts[0]), int(counts[1])
+        if n_items:
+            w = dv["dwork"][:n_items].cpu().numpy()
+            pages = (seq_lens.astype(np.int64) + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+            assert n_items <= self.items_cap and w[:, 0].min() >= 0 and w[:, 0].max() < B, "decode work item: row out of range"
+            assert (w[:, 1] >= 0).all() and (w[:, 1] <= w[:, 2]).all() and (w[:, 2] <= np.maximum(pages[w[:, 0]], 1)).all(), \
+                "decode work item: page range outside its sequence"
+            assert w[:, 3].max() < self.items_cap, "decode work item: partial slot past the workspace"
+            cover = np.bincount(w[:, 0], weights=w[:, 2] - w[:, 1], minlength=B)
+            nd_rows = np.unique(w[:, 0])
+            assert (cover[nd_rows] == np.maximum(pages[nd_rows], 1)).all(), "decode work list does not cover every page once"
+        if n_reds:
+            r = dv["dred"][:n_reds].cpu().numpy()
+            assert r[:, 0].max() < B and (r[:, 1] + r[:, 2]).max() <= self.items_cap, "decode reduce entry out of range"
         if n_cow:
             cow = dv["cow"][:2 * n_cow].cpu().numpy()
             assert cow.min() >= -1 and cow.max() < nb, f"copy-on-write page out of range: {cow}"
@@ -408,17 +521,22 @@ class ModelRunner:
         ev.record()
         return ("event", ev, (buf, S))
 
-    # ------------------------------------------------------------------ hipGraph decode
+    # ------------------------------------------------------------------ hipGraphs
     def _bucket_for(self, B: int) -> Optional[int]:
         for b in self.cfg.graph_batch_sizes:
             if b >= B and b <= self.cfg.sched.max_num_seqs:
                 return b
         return None
 
-    def _splits_for_bucket(self, bucket: int) -> int:
-        return ops.choose_decode_splits(bucket, self.local_kv_heads, min(self.cfg.sched.max_model_len, 2048))
+    def _pad_sampler_rows(self, lo: int, hi: int):
+        if hi > lo:
+            nv = self.nv
+            nv["temp"][lo:hi] = 0.0
+            nv["top_p"][lo:hi] = 1.0
+            nv["top_k"][lo:hi] = 0
 
     def _pad_decode(self, B: int, bucket: int):
+        """Rows ``B … bucket-1`` of a decode graph: no work item names them, their KV write is suppressed."""
         if bucket > B:
             nv = self.nv
             self.n_seq_lens[B:bucket] = 0
@@ -427,29 +545,64 @@ class ModelRunner:
             self.n_input[B:bucket] = 0
             self.n_qsl[B + 1:bucket + 1] = np.arange(B + 1, bucket + 1)
             nv["last"][B:bucket] = np.arange(B, bucket)
-            nv["temp"][B:bucket] = 0.0
-            nv["top_p"][B:bucket] = 1.0
-            nv["top_k"][B:bucket] = 0
             nv["src"][B:bucket] = -1
+            self._pad_sampler_rows(B, bucket)
 
-    def capture_graph(self, bucket: int):
-        """Capture one decode step at batch size ``bucket`` (inputs must be staged in the static buffers)."""
-        meta = self._meta(bucket, bucket, bucket, 0, self._splits_for_bucket(bucket), 0)
+    def _pad_mixed(self, T: int, S: int, tb: int, sb: int):
+        """Token rows ``T … tb-1`` of a mixed graph belong to no sequence (no KV write, no attention); sampled rows
+        ``S …`` point at token 0 and are sampled greedily into slots nobody reads."""
+        if tb > T:
+            self.n_slot[T:tb] = -1
+            self.n_pos[T:tb] = 0
+            self.n_input[T:tb] = 0
+        rows = self._mixed_caps(tb)[0]
+        self.nv["last"][S:max(rows, sb)] = 0
+        self._pad_sampler_rows(S, sb)
+
+    def _capture(self, key, run, warm: int = 2):
         stream = torch.cuda.Stream(device=self.device)
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):                      # warm-up outside capture (hipBLASLt workspaces, …)
-            for _ in range(2):
-                self._forward_sample(bucket, bucket, meta)
+            for _ in range(warm):
+                run()
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         before = dict(self.ctx.comm)
         with torch.cuda.graph(g, pool=self.graph_pool, stream=stream):
-            logits = self._forward_sample(bucket, bucket, meta)
+            out = run()
         comm = {k: v - before[k] for k, v in self.ctx.comm.items() if v != before[k]}
         if self.graph_pool is None:
             self.graph_pool = g.pool()
+        return g, out, comm
+
+    def capture_graph(self, bucket: int):
+        """Capture one decode step at batch size ``bucket`` (inputs must be staged in the static buffers)."""
+        items, reds = self._decode_caps(bucket)
+        meta = self._meta(bucket, bucket, bucket, items, reds, 0, counts_on_device=True)
+        g, logits, comm = self._capture(bucket, lambda: self._forward_sample(bucket, bucket, meta))
         self.graphs[bucket] = (g, meta, logits, comm)        # `logits`: the graph's own output buffer (self-test reads it)
+        return g
+
+    def capture_mixed_graph(self, tb: int):
+        """Body graph of a mixed (prefill + decode) step of up to ``tb`` tokens: forward pass over the padded token
+        rows, then the hidden states of the rows to sample gathered into the static ``h_last``."""
+        rows, items, reds, tiles = self._mixed_caps(tb)
+        meta = self._meta(rows, tb, rows, items, reds, tiles, counts_on_device=True)
+        dv = self.dv
+
+        def run():
+            h = self.model(dv["input"][:tb], meta, self.kv_caches)
+            torch.index_select(h, 0, dv["last"][:rows], out=self.h_last[:rows])
+            return h
+        g, h, comm = self._capture(("m", tb), run)
+        self.graphs[("m", tb)] = (g, meta, h, comm)
+        return g
+
+    def capture_head_graph(self, sb: int):
+        """LM head + sampler over the first ``sb`` rows of ``h_last``."""
+        g, logits, comm = self._capture(("h", sb), lambda: self._sample_rows(self.h_last[:sb], sb))
+        self.graphs[("h", sb)] = (g, None, logits, comm)
         return g
 
     # ------------------------------------------------------------------ fp8 KV calibration
@@ -492,7 +645,9 @@ class ModelRunner:
             nv["tile_seq"][:len(ts)] = ts
             nv["tile_q0"][:len(ts)] = t0
             self._copy_in()
-            return self._meta(1, n, 0, 0, 1, len(ts))
+            nv["counts"][:4] = (0, 0, len(ts), 0)
+            self._copy_in()
+            return self._meta(1, n, 0, 0, 0, len(ts))
 
         meta = stage(ids)
         for a in attns:
@@ -546,18 +701,20 @@ class ModelRunner:
         ts, t0 = ops.build_prefill_tiles(np.array([T], dtype=np.int32), 0, self.tile_tokens)
         nv["tile_seq"][:len(ts)] = ts
         nv["tile_q0"][:len(ts)] = t0
+        nv["counts"][:4] = (0, 0, len(ts), 0)
         self._copy_in()
-        h = self.model(self.dv["input"][:T], self._meta(1, T, 0, 0, 1, len(ts)), self.kv_caches)
+        h = self.model(self.dv["input"][:T], self._meta(1, T, 0, 0, 0, len(ts)), self.kv_caches)
         return self.model.compute_logits(h).float()
 
     # ------------------------------------------------------------------ start-up self-tests
-    def _stage_synthetic_decode(self, B: int, ctx_len: int = 24):
-        """A deterministic decode batch of ``B`` sequences (one page each) in the static buffers — the same on every
-        TP rank, so no broadcast is needed."""
+    def _stage_synthetic_decode(self, B: int, ctx_len: int = 24, prefill_len: int = 0, cap_items: int = 0):
+        """A deterministic batch of ``B`` decode rows (one page each) — plus, with ``prefill_len``, one fresh prompt of
+        that many tokens in the pages behind them — in the static buffers: the same on every TP rank, so no broadcast
+        is needed.  Returns the header fields ``(B, T, S, n_tiles, n_items, n_reds)``."""
         nv = self.nv
         i = np.arange(B)
         page = (i % self.num_blocks).astype(np.int32)
-        self.n_bt[:B] = 0
+        self.n_bt[:B + 1] = 0
         self.n_bt[:B, 0] = page
         self.n_seq_lens[:B] = ctx_len
         self.n_pos[:B] = ctx_len - 1
@@ -565,43 +722,67 @@ class ModelRunner:
         self.n_input[:B] = (i * 7 + 3) % self.cfg.model.vocab_size
         self.n_qsl[:B + 1] = np.arange(B + 1)
         nv["last"][:B] = i
-        nv["temp"][:B] = 0.0
-        nv["top_p"][:B] = 1.0
-        nv["top_k"][:B] = 0
-        nv["seeds"][:B] = 1
-        nv["steps"][:B] = 0
         nv["src"][:B] = -1
-        self._copy_in()
+        rows, T, n_tiles = B, B, 0
+        if prefill_len:
+            P = prefill_len
+            npg = (P + KV_BLOCK_SIZE - 1) // KV_BLOCK_SIZE
+            pages = B + np.arange(npg, dtype=np.int32)
+            assert B + npg <= self.num_blocks
+            t = np.arange(P)
+            self.n_input[B:B + P] = (t * 13 + 5) % self.cfg.model.vocab_size
+            self.n_pos[B:B + P] = t
+            self.n_slot[B:B + P] = pages[t // KV_BLOCK_SIZE] * KV_BLOCK_SIZE + t % KV_BLOCK_SIZE
+            self.n_bt[B, :npg] = pages
+            self.n_seq_lens[B] = P
+            self.n_qsl[B + 1] = B + P
+            nv["last"][B] = B + P - 1
+            ts, t0 = ops.build_prefill_tiles(np.array([P], dtype=np.int32), B, self.tile_tokens, self.n_seq_lens[B:B + 1])
+            n_tiles = len(ts)
+            nv["tile_seq"][:n_tiles] = ts
+            nv["tile_q0"][:n_tiles] = t0
+            rows, T = B + 1, B + P
+        nv["temp"][:rows] = 0.0
+        nv["top_p"][:rows] = 1.0
+        nv["top_k"][:rows] = 0
+        nv["seeds"][:rows] = 1
+        nv["steps"][:rows] = 0
+        n_items, n_reds, _ = self._stage_decode_work(B, cap_items)
+        nv["counts"][:4] = (n_items, n_reds, n_tiles, 0)
+        return rows, T, rows, n_tiles, n_items, n_reds
 
     def _vote(self, ok: bool) -> bool:
         return bool(self.ctx.all_min_int(1 if ok else 0))
+
+    def _compare_logits(self, eager, graph, ids_e, ids_g, extra: dict) -> tuple:
+        diff = float((eager - graph).abs().max())
+        scale = float(eager.abs().max())
+        ok = bool(diff == diff and diff <= 2e-2 * scale + 1e-3)
+        return ok, {**extra, "max_abs_logit_diff": round(diff, 6), "logit_scale": round(scale, 4),
+                    "greedy_agreement": float((ids_e == ids_g).float().mean())}
 
     @torch.inference_mode()
     def startup_selftest(self) -> dict:
         """Check the fast paths that change numerics-relevant execution against their plain counterparts, once, on
         every rank of the group; a path that fails (or raises) is switched off for the life of the engine and the
-        reason is kept in ``self.selftest`` (bench.py prints it).  Covered: a captured decode hipGraph against the
-        same step run eagerly (logit-level), and the GEMM/all-reduce pipeline of ``RowParallelLinear`` against
-        GEMM → all-reduce."""
+        reason is kept in ``self.selftest`` (bench.py prints it).  Covered: a captured decode hipGraph and a captured
+        mixed (prefill + decode) body + head graph pair against the same steps run eagerly (logit-level), and the
+        GEMM/all-reduce pipeline of ``RowParallelLinear`` against GEMM → all-reduce."""
         res = self.selftest
         if not self.on_gpu:
             return res
         # --- hipGraph replay vs eager, same staged batch
-        if self.cfg.use_hip_graphs and self.graphs:
+        decode_keys = [k for k in self.graphs if isinstance(k, int)]
+        if self.cfg.use_hip_graphs and decode_keys:
             try:
-                b = min([x for x in self.graphs if x >= 8] or list(self.graphs))
-                self._stage_synthetic_decode(b)
-                meta = self._meta(b, b, b, 0, self._splits_for_bucket(b), 0)
-                le = self._forward_sample(b, b, meta).float().clone()
+                b = min([x for x in decode_keys if x >= 8] or decode_keys)
+                rows, T, S, n_tiles, n_items, n_reds = self._stage_synthetic_decode(b, cap_items=self._decode_caps(b)[0])
+                self._copy_in()
+                le = self._forward_sample(b, b, self._meta(b, b, b, n_items, n_reds, 0)).float().clone()
                 ids_e = self.d_sampled[:b].clone()
                 self.graphs[b][0].replay()
-                lg = self.graphs[b][2].float()
-                diff = float((le - lg).abs().max())
-                scale = float(le.abs().max())
-                same_ids = float((ids_e == self.d_sampled[:b]).float().mean())
-                ok = bool(diff == diff and diff <= 2e-2 * scale + 1e-3)
-                res["graph_vs_eager"] = {"bucket": b, "max_abs_logit_diff": round(diff, 6), "logit_scale": round(scale, 4),
-                                         "greedy_agreement": same_ids}
+                ok, res["graph_vs_eager"] = self._compare_logits(le, self.graphs[b][2].float(), ids_e, self.d_sampled[:b],
+                                                                 {"bucket": b})
             except Exception as e:
                 ok = False
                 res["graph_vs_eager"] = {"error": f"{type(e).__name__}: {e}"}
@@ -611,6 +792,40 @@ class ModelRunner:
                 self.cfg.use_hip_graphs = False
                 self.graphs.clear()
                 print(f"[dli_amd] hipGraph decode disabled by the start-up self-test: {res['graph_vs_eager']}", flush=True)
+        # --- mixed step: body + head graphs vs eager
+        mixed_keys = [k[1] for k in self.graphs if isinstance(k, tuple) and k[0] == "m"]
+        if self.cfg.use_hip_graphs and self.cfg.mixed_step_graphs and mixed_keys:
+            try:
+                nd, P = 5, 40
+                tb = min([x for x in mixed_keys if x >= nd + P] or [max(mixed_keys)])
+                sb = self._bucket_for(nd + 1)
+                if tb < nd + P or not sb or self.num_blocks < nd + 3:
+                    raise RuntimeError("no bucket fits the synthetic mixed step")
+                rows, T, S, n_tiles, n_items, n_reds = self._stage_synthetic_decode(nd, prefill_len=P,
+                                                                                    cap_items=self._mixed_caps(tb)[1])
+                self._pad_mixed(T, S, tb, sb)
+                self._copy_in()
+                # eager over the SAME padded token rows (the GEMMs pick their kernels by row count: 45 rows and 64 rows
+                # differ by bf16 rounding noise, which is not what this test is about), exact launch extents
+                le = self._forward_sample(tb, S, self._meta(rows, tb, nd, n_items, n_reds, n_tiles)).float().clone()
+                ids_e = self.d_sampled[:S].clone()
+                if ("h", sb) not in self.graphs:
+                    self.capture_head_graph(sb)
+                self.graphs[("m", tb)][0].replay()
+                self.graphs[("h", sb)][0].replay()
+                ok, res["mixed_graph_vs_eager"] = self._compare_logits(le, self.graphs[("h", sb)][2][:S].float(), ids_e,
+                                                                       self.d_sampled[:S], {"tokens": T, "bucket": tb, "head": sb})
+            except Exception as e:
+                ok = False
+                res["mixed_graph_vs_eager"] = {"error": f"{type(e).__name__}: {e}"}
+            ok = self._vote(ok)
+            res["mixed_graph_vs_eager"]["ok"] = ok
+            if not ok:
+                self.cfg.mixed_step_graphs = False
+                for k in [k for k in self.graphs if isinstance(k, tuple)]:
+                    del self.graphs[k]
+                print(f"[dli_amd] mixed-step hipGraphs disabled by the start-up self-test: {res['mixed_graph_vs_eager']}",
+                      flush=True)
         # --- overlapped row-parallel linear vs plain
         if self.ctx.tp_size > 1:
             from ..models.layers import RowParallelLinear
@@ -641,26 +856,41 @@ class ModelRunner:
                           f"{res['overlapped_row_parallel']}", flush=True)
         return res
 
-    def capture_all(self, buckets=None):
-        """Pre-capture the decode graphs (largest first so that the pool is sized once).  Under TP every
-        rank must call this with the same buckets (the captures contain collectives)."""
+    def capture_all(self, buckets=None, mixed=None):
+        """Pre-capture the decode graphs, then the mixed-step body graphs and the head graphs (largest first so that the
+        pool is sized once).  Under TP every rank must call this with the same buckets (the captures contain
+        collectives).  Captures run on an empty step: no work item, no tile, every KV write suppressed."""
         if not (self.on_gpu and self.cfg.use_hip_graphs):
             return 0
         todo = [b for b in (buckets or self.cfg.graph_batch_sizes) if b <= self.cfg.sched.max_num_seqs]
         err = None
         try:
+            self.nv["counts"][:] = 0
             for bucket in sorted(todo, reverse=True):
                 if bucket in self.graphs:
                     continue
                 self._pad_decode(0, bucket)
                 self._copy_in()
                 self.capture_graph(bucket)
+            if self.cfg.mixed_step_graphs:
+                for tb in sorted(self.mixed_buckets if mixed is None else mixed, reverse=True):
+                    if ("m", tb) in self.graphs:
+                        continue
+                    self._pad_mixed(0, 0, tb, 0)
+                    self._copy_in()
+                    self.capture_mixed_graph(tb)
+                for sb in sorted(todo, reverse=True):
+                    if ("h", sb) not in self.graphs:
+                        self._pad_sampler_rows(0, sb)
+                        self.nv["last"][:sb] = 0
+                        self._copy_in()
+                        self.capture_head_graph(sb)
             torch.cuda.synchronize()
         except Exception as e:                               # e.g. a collective that cannot be captured on this backend
             err = f"{type(e).__name__}: {e}"
         if not self._vote(err is None):                      # all ranks keep their graphs, or none does
             self.selftest["graph_capture"] = {"ok": False, "error": err or "failed on another rank"}
-            print(f"[dli_amd] hipGraph capture failed ({self.selftest['graph_capture']['error']}): decode steps run eagerly",
+            print(f"[dli_amd] hipGraph capture failed ({self.selftest['graph_capture']['error']}): steps run eagerly",
                   flush=True)
             self.cfg.use_hip_graphs = False
             self.graphs.clear()

@@ -550,3 +550,33 @@ def test_comm_fault_discards_the_suspect_steps_and_recomputes(pipelined):
     assert [got[f"q{i}"] for i in range(3)] == want
     assert eng.metrics.comm_fault_recoveries == 1
     assert eng.bm.num_free == eng.bm.num_blocks
+
+
+def test_decode_work_list_covers_every_page_once_and_respects_caps():
+    """ops.build_decode_work: equal-size page ranges per row, every page in exactly one range, partial slots dense and
+    consistent with the reduce list, item count under the cap (chunks double until it fits)."""
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 300, 1500):
+        L = np.clip(rng.lognormal(6.1, 0.8, size=n), 1, 2048).astype(np.int64)
+        pages = (L + 31) // 32
+        for cap in (0, 3 * n, n + 5, n):
+            work, red, n_parts = ops.build_decode_work(L, 8, cap)
+            assert cap == 0 or len(work) <= max(cap, n)
+            cover = np.zeros(n, dtype=np.int64)
+            np.add.at(cover, work[:, 0], work[:, 2] - work[:, 1])
+            assert (cover == pages).all() and (work[:, 2] > work[:, 1]).all()
+            multi = work[work[:, 3] >= 0]
+            assert len(multi) == n_parts and sorted(multi[:, 3].tolist()) == list(range(n_parts))
+            for row, first, k, _ in red:
+                mine = work[work[:, 0] == row]
+                assert len(mine) == k and mine[:, 3].tolist() == list(range(first, first + k))
+            single = work[work[:, 3] < 0]
+            assert len(set(single[:, 0].tolist()) & set(red[:, 0].tolist())) == 0
+            if n * 8 >= 512:
+                assert len(work) == n and len(red) == 0     # big batches: one range per row (measured fastest), no reduce
+            elif cap == 0:
+                assert len(work) > n                        # small batches: long rows are cut to fill the chip
+    items, reds = ops.decode_launch_caps(8, 8)
+    L = np.array([40, 2048, 2048, 100, 5, 2048, 700, 2048])
+    work, red, _ = ops.build_decode_work(L, 8, items)
+    assert len(work) <= items and len(red) <= reds and (np.bincount(work[:, 0])[[0, 3, 4]] == 1).all()

@@ -85,6 +85,37 @@ def test_startup_selftest_pins_graph_replay_to_eager_at_logit_level():
     assert st["greedy_agreement"] == 1.0
 
 
+def test_mixed_step_graphs_equal_eager_and_cover_the_prefill_steps():
+    """steps that hold prefill chunks replay a body graph (token bucket) + a head graph (sampled-row
+    bucket) with all attention work taken from device-side lists.  Requests arrive staggered so that most steps mix
+    running decodes with new prefill chunks; the greedy output must match the eager engine's, nearly every step must
+    be a graph replay, and the start-up self-test pins a mixed step graph-vs-eager at logit level."""
+    p = SamplingParams(temperature=0.0, max_tokens=24, ignore_eos=True)
+    prompts = _prompts(7, (5, 70, 33, 200, 130, 90, 260, 17))
+
+    def run(graphs):
+        eng = make(graphs=graphs, buckets=(1, 2, 4, 8), chunk=64)
+        eng.warmup()
+        outs = {}
+        nxt = 0
+        while eng.has_unfinished() or nxt < len(prompts):
+            if nxt < len(prompts) and (not eng.has_unfinished() or eng.metrics.steps % 3 == 0):
+                eng.add_request(f"r{nxt}", prompt_ids=prompts[nxt], params=p)
+                nxt += 1
+            for o in eng.step():
+                outs.setdefault(o.req_id, []).extend(o.new_token_ids)
+        return eng, [outs[f"r{i}"] for i in range(len(prompts))]
+
+    _, eager = run(False)
+    eng, graph = run(True)
+    st = eng.runner.stats
+    assert st["mixed_graph_steps"] >= 10 and st["eager_steps"] <= 2, st
+    agree = np.mean([np.mean(np.array(a) == np.array(b)) for a, b in zip(eager, graph)])
+    assert all(a[:4] == b[:4] for a, b in zip(eager, graph)) and agree > 0.9, (agree, eager, graph)
+    sm = eng.runner.selftest["mixed_graph_vs_eager"]
+    assert sm["ok"] is True and sm["greedy_agreement"] == 1.0 and sm["max_abs_logit_diff"] <= 2e-3 * max(sm["logit_scale"], 1.0), sm
+
+
 def test_chunked_prefill_equals_single_shot_on_gpu():
     p = SamplingParams(temperature=0.0, max_tokens=8, ignore_eos=True)
     a = make(graphs=False, chunk=32).generate(None, p, prompt_ids=_prompts(5))

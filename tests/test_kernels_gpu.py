@@ -162,6 +162,53 @@ def test_paged_attention_decode(Hq, Hkv, splits, kv_dtype):
     assert got[7].abs().max() == 0                                  # empty (padded) sequence → zeros
 
 
+@pytest.mark.parametrize("Hq,Hkv", [(32, 8), (8, 1)])
+@pytest.mark.parametrize("wl", [dict(), dict(chunk_pages=4), dict(chunk_pages=16), dict(cap_items=10), dict(launch_items=64)])
+@pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float8_e4m3fn])
+def test_paged_attention_decode_work_list(Hq, Hkv, wl, kv_dtype):
+    """Work-list decode: ragged page ranges per sequence — one range for short rows, several
+    equal-size ones for long rows, combined by the variable-count reduce — against the fp32 reference; also with the
+    list squeezed under a cap (bigger chunks) and with a launch grid larger than the list (what a hipGraph replays:
+    the surplus workgroups must leave on the device-side count)."""
+    seq_lens = [1, 31, 32, 33, 700, 2048, 129, 1000, 65]
+    scales = (0.5, 0.25) if kv_dtype == torch.float8_e4m3fn else (1.0, 1.0)
+    kc, vc, bt = _fill_cache(Hq, Hkv, seq_lens, kv_dtype, seed=21, scales=scales)
+    B = len(seq_lens)
+    qkv = _bf(B, (Hq + 2 * Hkv) * 128, seed=22)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    qsl = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    meta = ops.AttnMetadata(num_decode=B, num_prefill=0, num_tokens=B, positions=None, slot_mapping=None,
+                            block_tables=bt, seq_lens=sl, query_start_loc=qsl)
+    ops.attach_decode_worklist(meta, np.array(seq_lens), Hq, Hkv, DEV, **wl)
+    n_items = int(meta.counts[0])
+    if "cap_items" in wl:
+        assert n_items <= 10
+    if "chunk_pages" in wl:
+        assert n_items > B                                          # the long rows really were cut
+    scale = 1 / math.sqrt(128)
+    out = torch.full((B, Hq * 128), 7.0, dtype=torch.bfloat16, device=DEV)
+    got = ops.paged_attention(qkv, kc, vc, meta, Hq, Hkv, 128, scale, *scales, out=out).float()
+    want = ref.paged_attention_ref(qkv[:, :Hq * 128].reshape(B, Hq, 128), kc, vc, bt, sl, qsl, scale, *scales).float()
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2)
+
+
+def test_decode_work_list_equals_uniform_splits_bitwise_on_single_range_rows():
+    """Rows that fit one range take the same code path as the uniform kernel with one split: identical bits."""
+    Hq, Hkv = 32, 8
+    seq_lens = [5, 64, 100, 127]
+    kc, vc, bt = _fill_cache(Hq, Hkv, seq_lens, torch.bfloat16, seed=31)
+    B = len(seq_lens)
+    qkv = _bf(B, (Hq + 2 * Hkv) * 128, seed=32)
+    sl = torch.tensor(seq_lens, dtype=torch.int32, device=DEV)
+    qsl = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+    m1 = ops.AttnMetadata(B, 0, B, None, None, bt, sl, qsl, decode_splits=1)
+    m2 = ops.attach_decode_worklist(ops.AttnMetadata(B, 0, B, None, None, bt, sl, qsl), np.array(seq_lens), Hq, Hkv, DEV)
+    a = ops.paged_attention(qkv, kc, vc, m1, Hq, Hkv, 128, 0.088)
+    b = ops.paged_attention(qkv, kc, vc, m2, Hq, Hkv, 128, 0.088)
+    assert torch.equal(a, b)
+
+
 def test_decode_softmax_rescale_branch():
     """One key dominates late in the sequence: forces a large running-max jump (guide rule 26)."""
     Hq, Hkv, L = 32, 8, 300
