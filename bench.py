@@ -68,6 +68,10 @@ def parse(argv=None):
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree of one replica (dp = gpus / tp)")
     ap.add_argument("--ep", type=int, default=1, help="expert-parallel degree (1 or tp; MoE models)")
+    ap.add_argument("--emulate-tp", type=int, default=0,
+                    help="run ONE rank (TP rank 0) of a replica of this TP degree on one GPU: that rank's exact shards, every "
+                         "collective replaced by a same-bytes device copy, load found by the capacity probe.  A workload "
+                         "study (GPU-busy, host time per step, kernel mix) — the line is marked INVALID as a throughput figure")
     ap.add_argument("--qps", type=float, default=float(os.environ.get("DLI_BENCH_QPS", "0")),
                     help="offered load per replica (requests/s); 0: the model's default")
     ap.add_argument("--ramp-seconds", type=float, default=30.0,
@@ -266,6 +270,12 @@ def main():
                            ep_a2a_min_tokens=args.ep_a2a_min_tokens)
     dev, ctx = job.device, job.ctx
     rank, world = layout.rank, layout.world
+    if args.emulate_tp > 1:
+        if world != 1 or args.tp != 1:
+            raise SystemExit("--emulate-tp runs one rank on one GPU: use it with --gpus 1 and without --tp")
+        from dli_amd.parallel.state import ParallelContext
+        ctx = ParallelContext(tp_size=args.emulate_tp, tp_rank=0, ep_size=args.emulate_tp if args.ep > 1 else 1, emulated=True)
+        job.comm["device_backend"] = f"emulated (rank 0 of tp{args.emulate_tp}: collectives are same-bytes device copies)"
     note(f"{world} rank(s) up: device backend {job.comm['device_backend']}, custom all-reduce "
          f"{job.comm['custom_ar_enabled']}, devices {job.comm['device_ids']}")
 
@@ -277,11 +287,12 @@ def main():
     slo = slo_rows[args.slo]
     # offered load per replica: --qps, else the model's measured 1-GPU rate; a TP replica without --qps measures its own
     # capacity first (run_fixed → capacity_probe) — the figure here is then only the probe's starting point
-    qps = args.qps or DEFAULT_QPS.get(args.model, 20.0) * (1.0 if args.tp == 1 else 0.6 * args.tp)
+    tp_eff = max(args.tp, args.emulate_tp)
+    qps = args.qps or DEFAULT_QPS.get(args.model, 20.0) * (1.0 if tp_eff == 1 else 0.6 * tp_eff)
     if not args.max_num_seqs:
-        args.max_num_seqs = 2048 if args.tp <= 2 else 4096
+        args.max_num_seqs = 2048 if tp_eff <= 2 else 4096
     if not args.max_batched_tokens:
-        args.max_batched_tokens = 4096 if args.tp <= 2 else 8192
+        args.max_batched_tokens = 4096 if tp_eff <= 2 else 8192
     over = {"num_layers": args.num_layers} if args.num_layers else {}
     mcfg = get_model_config(args.model, **over)
     qdelay = args.max_queue_delay if args.max_queue_delay is not None else 4.0 * slo[0]
@@ -292,8 +303,9 @@ def main():
                                              ttft_slo=None if args.fcfs else slo[0],
                                              tpot_slo=slo[1] if args.tpot_control else None,
                                              max_queue_delay=None if args.fcfs else qdelay),
-                       parallel=ParallelConfig(tp=args.tp, ep=args.ep, custom_all_reduce=not args.no_custom_ar,
-                                               ep_a2a_min_tokens=args.ep_a2a_min_tokens),
+                       parallel=ParallelConfig(tp=tp_eff, ep=args.ep if args.emulate_tp <= 1 else (tp_eff if args.ep > 1 else 1),
+                                               custom_all_reduce=not args.no_custom_ar,
+                                               ep_a2a_min_tokens=0 if args.emulate_tp > 1 else args.ep_a2a_min_tokens),
                        device=args.device, seed=args.seed, use_hip_graphs=on_gpu and not args.no_graphs,
                        async_scheduling=False if args.sync_steps else None, mixed_step_graphs=not args.no_mixed_graphs)
     t_load = time.perf_counter()
@@ -356,6 +368,10 @@ def main():
             "load_s": round(t_load, 1), "kv_cache_tokens": eng.runner.kv_cache_tokens,
             "self_launched": os.environ.get("DLI_SELF_LAUNCHED") == "1",
         })
+        if args.emulate_tp > 1:
+            line["config"]["parallelism"] = f"tp{args.emulate_tp} rank 0 emulated on 1 GPU" + (f"+ep{args.emulate_tp}" if args.ep > 1 else "")
+            line["INVALID_emulation"] = (f"one rank's share of a tp{args.emulate_tp} replica with device copies in place of the "
+                                         "collectives: a workload study, not a throughput figure of any configuration")
         if args.num_layers:
             line["INVALID_reduced_model"] = f"--num-layers {args.num_layers}: rehearsal, not the named architecture"
         print(json.dumps(line), file=result_out, flush=True)
@@ -376,12 +392,14 @@ def make_share(args, mcfg, layout, qps, seconds, seed):
 
 
 def capacity_probe(args, eng, mcfg, layout, qps_guess, sync_drivers, agree, note):
-    """Offered load for a replica nobody has measured yet (``--tp`` > 1 without ``--qps``): saturate it for
-    ``--capacity-probe-seconds`` (3 × the guess, shedding on), take the token rate of the second half and divide by the
-    trace's mean tokens per request → requests/s the replica can complete; offer 0.9 × the smallest replica's figure."""
+    """Offered load for a replica nobody has measured yet (``--tp`` > 1 without ``--qps``): SATURATE it for
+    ``--capacity-probe-seconds`` (4 × the guess — the guess itself is 0.6 × tp × the 1-GPU rate, so this is ≈ 2.4 × what
+    perfect scaling could serve; shedding on), take the token rate of the second half and divide by the trace's mean
+    tokens per request → requests/s the replica can complete; offer 0.9 × the smallest replica's figure."""
     import numpy as np
     secs = args.capacity_probe_seconds
-    stamps, n_in, n_out = make_share(args, mcfg, layout, 3.0 * qps_guess, secs + 5.0, args.seed + 991)
+    probe_qps = 4.0 * qps_guess
+    stamps, n_in, n_out = make_share(args, mcfg, layout, probe_qps, secs + 5.0, args.seed + 991)
     rp = Replay(eng, mcfg.vocab_size, stamps, n_in, n_out, args.seed * 1000 + 500 + layout.replica)
     rp.tag = "cap"
     sync_drivers()
@@ -390,11 +408,14 @@ def capacity_probe(args, eng, mcfg, layout, qps_guess, sync_drivers, agree, note
     tok0, t_a = eng.metrics.step_tokens, time.perf_counter()
     rp.run_for(secs / 2)
     tok_s = (eng.metrics.step_tokens - tok0) / max(time.perf_counter() - t_a, 1e-6)
+    pop_end = rp.population
     rp.drain()
     per_req = float(np.mean(n_in + n_out))
     est = tok_s / per_req
     est_all = agree(int(est * 1000), "min") / 1000.0
-    info = {"seconds": secs, "offered_qps_during_probe": round(3.0 * qps_guess, 3), "tok_per_s": round(tok_s, 1),
+    saturated = pop_end > 0.25 * probe_qps * secs / 2          # a backlog built up: the rate is the replica's, not the trace's
+    info = {"seconds": secs, "offered_qps_during_probe": round(probe_qps, 3), "saturated": bool(saturated),
+            "in_system_at_end": int(pop_end), "tok_per_s": round(tok_s, 1),
             "mean_tokens_per_request": round(per_req, 1), "est_req_per_s": round(est, 3),
             "est_req_per_s_min_over_replicas": round(est_all, 3), "offered_fraction": 0.9}
     note(f"capacity probe: {tok_s:.0f} tok/s ≈ {est:.2f} req/s per replica → offering {0.9 * est_all:.2f}")
@@ -404,7 +425,7 @@ def capacity_probe(args, eng, mcfg, layout, qps_guess, sync_drivers, agree, note
 def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu, agree, note):
     import numpy as np
     probe = None
-    if layout.tp > 1 and not args.qps and args.capacity_probe_seconds > 0:
+    if (layout.tp > 1 or args.emulate_tp > 1) and not args.qps and args.capacity_probe_seconds > 0:
         qps, probe = capacity_probe(args, eng, mcfg, layout, qps, sync_drivers, agree, note)
     # an upper bound of the replay length: the ramp plus the steps at a pessimistic 0.25 s each
     horizon = args.ramp_cap_seconds + args.sustained_seconds + (args.steps + args.warmup) * 0.25 + 60.0
@@ -443,7 +464,8 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu,
     n_done_before, n_inj_before, shed_before = len(rp.done), rp.nxt, rp.shed
     late_before = len(eng.scheduler.late)
     m = eng.metrics
-    before = (m.steps, m.step_tokens, m.sched_time, m.exec_time, m.post_time, dict(eng.runner.stats), dict(ctx.comm))
+    before = (m.steps, m.step_tokens, m.sched_time, m.exec_time, m.post_time, dict(eng.runner.stats), dict(ctx.comm),
+              m.launch_time)
     t_start = time.perf_counter()
     beat = t_start
     for i in range(args.steps):
@@ -471,6 +493,7 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu,
         "out_tokens": int(sum(r.num_output for r in fin)), "in_tokens": int(sum(r.num_prompt for r in fin)),
         "step_tokens": m.step_tokens - before[1],
         "sched_s": m.sched_time - before[2], "exec_s": m.exec_time - before[3], "post_s": m.post_time - before[4],
+        "launch_s": m.launch_time - before[7],
         "graph_steps": eng.runner.stats["graph_steps"] - before[5]["graph_steps"],
         "mixed_graph_steps": eng.runner.stats["mixed_graph_steps"] - before[5]["mixed_graph_steps"],
         "eager_steps": eng.runner.stats["eager_steps"] - before[5]["eager_steps"],
@@ -534,6 +557,8 @@ def fixed_line(args, allstats, layout, slo, qps, mcfg):
         "tpot_p50_s": pct(all_tpot, 50), "tpot_p99_s": pct(all_tpot, 99),
         "output_tok_per_s": round(sum(s["out_tokens"] for s in allstats) / T, 1),
         "total_tok_per_s": round(sum(s["step_tokens"] for s in allstats) / T, 1),
+        "host_ms_per_step": {k: round(sum(s[k + "_s"] for s in allstats) / (steps * len(allstats)) * 1e3, 3)
+                             for k in ("sched", "launch", "post")},
         "all_reduce_calls_per_step": per_step("ar_custom_calls") + per_step("ar_lib_calls"),
         "all_reduce_bytes_per_step": per_step("ar_custom_bytes") + per_step("ar_lib_bytes"),
         "comm_per_step": {k: per_step(k) for k in comm},

@@ -63,6 +63,15 @@ MODEL_PRESETS: dict[str, ModelConfig] = {
                             intermediate_size=3072, num_layers=12, num_heads=12, num_kv_heads=12,
                             head_dim=64, max_position=2048, pos_offset=2, tie_embeddings=True,
                             dtype="float32", bos_token_id=2, eos_token_id=2),
+    # ONE tensor-parallel rank's share of the 8-GPU configs as a plain model (kernel benchmarks / single-GPU studies of
+    # the shard shapes; `bench.py --emulate-tp 8` gets the same shapes from the real presets by sharding):
+    # Llama-3-70B / 8: 8 Q + 1 KV heads, FFN 3584, vocabulary 16032; Mixtral-8x7B / 8 with EP = 8: 4 Q + 1 KV heads and
+    # ONE whole expert per rank (the router is approximated by top-1 of 1: every token takes the expert)
+    "llama3-70b-tp8shard": ModelConfig(name="llama3-70b-tp8shard", vocab_size=16032, hidden_size=8192,
+                                       intermediate_size=3584, num_layers=80, num_heads=8, num_kv_heads=1),
+    "mixtral-8x7b-ep8shard": ModelConfig(name="mixtral-8x7b-ep8shard", arch="mixtral", vocab_size=4000, hidden_size=4096,
+                                         intermediate_size=14336, num_layers=32, num_heads=4, num_kv_heads=1,
+                                         rope_theta=1e6, max_position=32768, num_experts=1, top_k_experts=1),
     # tiny shapes for CPU tests / smoke (same code paths, seconds to run)
     "tiny-llama": ModelConfig(name="tiny-llama", vocab_size=512, hidden_size=128, intermediate_size=256,
                               num_layers=2, num_heads=8, num_kv_heads=2, head_dim=16, max_position=512,

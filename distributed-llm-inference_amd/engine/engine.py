@@ -57,7 +57,7 @@ class LLMEngine:
         one at a time."""
         if not self.runner.on_gpu:
             return False
-        if self.ctx.tp_size > 1:
+        if self.ctx.distributed:
             import torch.distributed as dist
             return dist.get_backend(self.ctx.group) == "nccl"
         return True
@@ -125,7 +125,7 @@ class LLMEngine:
         drains between steps.  Ids the host has not seen yet are fed from the sampler's device buffer
         (``ops.gather_sampled``); an EOS discovered one step late costs one discarded token.
         Unpipelined: schedule → run → wait → outputs, nothing in flight between calls."""
-        if not self._warmed and self.ctx.tp_size > 1:
+        if not self._warmed and self.ctx.distributed:
             self.warmup()                                    # the TP workers are waiting in theirs (collective)
         t0 = time.perf_counter()
         with trace_range("schedule"):
@@ -136,13 +136,14 @@ class LLMEngine:
             for r in batch.requests:
                 if r.first_scheduled is None:
                     r.first_scheduled = t1
-            if self.ctx.tp_size > 1 and self.metrics.steps % 128 == 0:
+            if self.ctx.distributed and self.metrics.steps % 128 == 0:
                 from ..runtime.tp_launcher import check_children
                 check_children()                             # a dead TP worker would hang the next collective
                 # (a timed-out custom all-reduce is seen behind EVERY step without a sync and switches the group to
                 #  the library collectives with the next step header: ModelRunner._note_ar_error / _broadcast_step)
             with trace_range(f"launch[T={batch.total_tokens},B={len(batch.requests)}]"):
                 handle = self.runner.launch(batch, self.bm, self.scheduler.take_copies())
+                self.metrics.launch_time += time.perf_counter() - t1     # host: stage + queue the step's kernels / graphs
                 self.scheduler.advance(batch, self.cfg.sched.max_model_len)
                 for child in self.scheduler.forked:          # n > 1: children forked off a prompt that just completed
                     self.requests[child.req_id] = child
@@ -263,6 +264,6 @@ class LLMEngine:
         self.ctx.barrier()
 
     def shutdown(self):
-        if not self._warmed and self.ctx.tp_size > 1 and self.ctx.is_driver:
+        if not self._warmed and self.ctx.distributed and self.ctx.is_driver:
             self.warmup()                                    # release the workers from their warm-up barrier first
         self.runner.shutdown_workers()

@@ -54,6 +54,7 @@ class EngineMetrics:
         self.kv_used_frac = 0.0
         self.preemptions = 0
         self.sched_time = 0.0
+        self.launch_time = 0.0
         self.exec_time = 0.0
         self.post_time = 0.0
         self.ttft = Histogram(_TTFT_BUCKETS)
@@ -116,6 +117,7 @@ class EngineMetrics:
             ("dli_last_batch_tokens", "gauge", "tokens in the most recent step", self.last_batch_tokens),
             ("dli_last_batch_seqs", "gauge", "sequences in the most recent step", self.last_batch_seqs),
             ("dli_schedule_seconds_total", "counter", "host time in the scheduler", self.sched_time),
+            ("dli_launch_seconds_total", "counter", "host time staging a step and queueing its kernels / graph launches", self.launch_time),
             ("dli_execute_seconds_total", "counter", "time in model execution (incl. sync)", self.exec_time),
             ("dli_postprocess_seconds_total", "counter", "host time after execution", self.post_time),
         ]

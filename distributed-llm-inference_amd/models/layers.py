@@ -112,7 +112,7 @@ class RowParallelLinear(nn.Module):
     def forward(self, x):
         # the bias must be added once, not tp times: only rank 0 adds it before the reduction
         b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
-        if (self.reduce and self.OVERLAP_OK and self.ctx.tp_size > 1 and x.is_cuda and x.dim() == 2
+        if (self.reduce and self.OVERLAP_OK and self.ctx.distributed and x.is_cuda and x.dim() == 2
                 and x.shape[0] >= self.OVERLAP_MIN_ROWS and self._stream_ordered_backend() and not torch.cuda.is_current_stream_capturing()):
             return self._forward_overlapped(x, b)
         y = ops.linear(x, self.weight.data, b)

@@ -33,6 +33,11 @@ class ParallelContext:
     ep_size: int = 1                      # expert-parallel degree (1 or tp_size)
     custom_ar: Optional[Any] = None       # parallel.custom_all_reduce.CustomAllReduce
     ep_a2a_min_tokens: int = 0            # MoE steps of at least this many tokens dispatch by all-to-all (0: never)
+    # ONE rank of a tp_size-wide group run alone (bench.py --emulate-tp): the model holds exactly TP rank `tp_rank`'s
+    # shards (heads, FFN columns, vocabulary slice, experts), and every collective is replaced by a device copy of the
+    # same bytes — the rank's GEMM / attention shapes, kernel count and host work per step are the real ones, the link
+    # time is not.  Measures what one GPU of an 8-GPU replica has to do, on the one GPU there is.
+    emulated: bool = False
     # calls / bytes per collective kind and path since start-up (host-side counts; a hipGraph replay adds the
     # counts recorded at its capture, see ModelRunner)
     comm: dict = field(default_factory=lambda: {"ar_custom_calls": 0, "ar_custom_bytes": 0, "ar_lib_calls": 0,
@@ -44,11 +49,18 @@ class ParallelContext:
         return self.tp_rank == 0
 
     @property
+    def distributed(self) -> bool:
+        """More than one process takes part (False for a single rank and for an emulated rank)."""
+        return self.tp_size > 1 and not self.emulated
+
+    @property
     def ep_rank(self) -> int:
         return self.tp_rank if self.ep_size > 1 else 0
 
     @property
     def device_backend(self) -> str:
+        if self.emulated:
+            return "emulated"
         if self.tp_size == 1 or self.group is None:
             return "none"
         return dist.get_backend(self.group)
@@ -62,6 +74,12 @@ class ParallelContext:
         if self.tp_size == 1:
             return x
         c = self.comm
+        if self.emulated:
+            c["ar_custom_calls"] += 1
+            c["ar_custom_bytes"] += x.numel() * x.element_size()
+            out = torch.empty_like(x)
+            out.copy_(x)                                     # same bytes read + written as the message, no peers
+            return out
         if self.custom_ar is not None and self.custom_ar.should_use(x):
             c["ar_custom_calls"] += 1
             c["ar_custom_bytes"] += x.numel() * x.element_size()
@@ -88,6 +106,7 @@ class ParallelContext:
         GPUs).  The split sizes are host integers — the caller has exchanged the counts beforehand."""
         if self.tp_size == 1:
             return x
+        assert not self.emulated, "an emulated rank has no peers to exchange rows with (ep_a2a_min_tokens must be 0)"
         out = torch.empty((int(sum(out_rows)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
         self.comm["a2a_calls"] += 1
         self.comm["a2a_bytes"] += x.numel() * x.element_size()
@@ -110,6 +129,8 @@ class ParallelContext:
         rows = x2.shape[0]
         self.comm["ag_calls"] += 1
         self.comm["ag_bytes"] += x2.numel() * x2.element_size()
+        if self.emulated:
+            return x2.repeat(1, self.tp_size).reshape(*lead, self.tp_size * n)    # tp copies of the local slice
         if self.custom_ar is not None and self.custom_ar.should_use(x2):
             out = self.custom_ar.all_gather(x2)
             return out.permute(1, 0, 2).reshape(*lead, self.tp_size * n)
@@ -130,6 +151,8 @@ class ParallelContext:
         x = x.contiguous()
         self.comm["ag_calls"] += 1
         self.comm["ag_bytes"] += x.numel() * x.element_size()
+        if self.emulated:
+            return x.repeat((self.tp_size,) + (1,) * (x.dim() - 1))
         if self.custom_ar is not None and self.custom_ar.should_use(x):
             return self.custom_ar.all_gather(x).reshape((self.tp_size * x.shape[0],) + tuple(x.shape[1:]))
         out = torch.empty((self.tp_size * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -139,7 +162,7 @@ class ParallelContext:
     def broadcast_tensor(self, x: torch.Tensor, src: int = 0) -> torch.Tensor:
         """In place broadcast from TP rank ``src``: the IPC kernel when it is up (no library call on the step path),
         the device group's broadcast otherwise."""
-        if self.tp_size > 1:
+        if self.distributed:
             self.comm["bcast_calls"] += 1
             self.comm["bcast_bytes"] += x.numel() * x.element_size()
             if self.custom_ar is not None and self.custom_ar.can_broadcast(x):
@@ -150,7 +173,7 @@ class ParallelContext:
         return x
 
     def broadcast_object(self, obj, src: int = 0):
-        if self.tp_size == 1:
+        if not self.distributed:
             return obj
         box = [obj]
         g = self.cpu_group if self.cpu_group is not None else self.group
@@ -158,12 +181,12 @@ class ParallelContext:
         return box[0]
 
     def barrier(self):
-        if self.tp_size > 1:
+        if self.distributed:
             dist.barrier(group=self.cpu_group if self.cpu_group is not None else self.group)
 
     def all_min_int(self, value: int) -> int:
         """Minimum of a host integer over the TP group (KV-cache sizing: every rank must agree on the page count)."""
-        if self.tp_size == 1:
+        if not self.distributed:
             return int(value)
         t = torch.tensor([int(value)], dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.cpu_group if self.cpu_group is not None else self.group)

@@ -71,7 +71,7 @@ class ModelRunner:
         self.kv_caches = allocate_kv_cache(mcfg.num_layers, self.num_blocks, self.local_kv_heads, mcfg.head_dim,
                                            self.kv_dtype, device)
         self._alloc_buffers()
-        if self.ctx.tp_size > 1 and self.on_gpu and cfg.use_hip_graphs:
+        if self.ctx.distributed and self.on_gpu and cfg.use_hip_graphs:
             import torch.distributed as dist
             if dist.get_backend(self.ctx.group) != "nccl" and self.ctx.custom_ar is None:
                 cfg.use_hip_graphs = False                   # gloo collectives synchronise the host: not capturable
@@ -324,7 +324,7 @@ class ModelRunner:
         if tb and n_tiles > self._mixed_caps(tb)[3]:
             tb = sb = 0                                      # more prefill sequences than the graph's tile grid: eager
         header = (B, T, S, nd, n_tiles, bucket, n_items, n_src, len(cow), n_reds, tb, sb)
-        if self.ctx.tp_size > 1:
+        if self.ctx.distributed:
             self._broadcast_step(header)
         return self.run_staged(header)
 
@@ -400,7 +400,7 @@ class ModelRunner:
         return True
 
     def shutdown_workers(self):
-        if self.ctx.tp_size > 1 and self.ctx.is_driver:
+        if self.ctx.distributed and self.ctx.is_driver:
             import torch.distributed as dist
             g = self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
             hdr = torch.zeros(self.HEADER_FIELDS + 1, dtype=torch.int64)
@@ -417,7 +417,7 @@ class ModelRunner:
     @torch.inference_mode()
     def run_staged(self, header, staged_on_device: bool = False):
         B, T, S, nd, n_tiles, bucket, n_items, n_src, n_cow, n_reds, tb, sb = header
-        tp_staged = self.ctx.tp_size > 1                    # _broadcast_step already padded + copied
+        tp_staged = self.ctx.distributed                    # _broadcast_step already padded + copied
         if not tp_staged:
             self._pad_for(header)
             self._copy_in()
@@ -827,7 +827,7 @@ class ModelRunner:
                 print(f"[dli_amd] mixed-step hipGraphs disabled by the start-up self-test: {res['mixed_graph_vs_eager']}",
                       flush=True)
         # --- overlapped row-parallel linear vs plain
-        if self.ctx.tp_size > 1:
+        if self.ctx.distributed:
             from ..models.layers import RowParallelLinear
             layer = next((m for m in self.model.modules() if isinstance(m, RowParallelLinear) and m.reduce), None)
             if layer is None or not layer._stream_ordered_backend():

@@ -156,3 +156,33 @@ def test_tp_replica_without_qps_probes_its_capacity_and_reports_steady_fields():
     assert isinstance(d["steady"], bool) and d["ramp_s"] >= 2.0 and "value_window" in d
     assert d["value"] == d["value_sustained"] and d["value_source"].startswith("value_sustained")
     assert d["config"]["max_num_batched_tokens"] == 256
+
+
+def test_emulated_tp_rank_runs_alone_with_the_shard_shapes():
+    """`bench.py --emulate-tp N`: one process, TP rank 0's shards of an N-wide replica, collectives
+    replaced by same-bytes copies — counted like real ones — and the line is marked as not a throughput figure."""
+    common = [x for i, x in enumerate(COMMON) if x != "--qps" and COMMON[i - 1] != "--qps"]
+    p, lines = run_bench(["--model", "tiny-llama-8kv", "--emulate-tp", "8", "--capacity-probe-seconds", "2"], common=common)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "INVALID_emulation" in d and d["config"]["parallelism"].startswith("tp8 rank 0 emulated")
+    assert d["all_reduce_calls_per_step"] == pytest.approx(5.0) and d["comm_per_step"]["ag_calls"] > 0
+    assert d["capacity_probe"]["est_req_per_s"] > 0 and set(d["host_ms_per_step"]) == {"sched", "launch", "post"}
+
+
+def test_emulated_rank_holds_exactly_rank_zero_shards():
+    import torch
+    from dli_amd.config import get_model_config
+    from dli_amd.models import build_model
+    from dli_amd.parallel.state import ParallelContext
+    cfg = get_model_config("tiny-mixtral-8e")
+    full = build_model(cfg, device="cpu", dtype=torch.float32, seed=3)
+    emu = build_model(cfg, ParallelContext(tp_size=8, tp_rank=0, ep_size=8, emulated=True), "cpu", torch.float32, 3)
+    fw = {n: w for n, w, _ in full.named_weights()}
+    for name, w, _ in emu.named_weights():
+        assert torch.equal(w.data, w.shard_of(fw[name].data)), name
+    l0 = emu.layers[0]
+    assert l0.attn.hq == 2 and l0.attn.hkv == 1 and l0.mlp.w13.data.shape[0] == 1 and l0.mlp.local_experts == 1
+    x = torch.randn(4, cfg.hidden_size)
+    assert emu.ctx.all_reduce(x) is not x and torch.equal(emu.ctx.all_reduce(x), x)
+    assert emu.ctx.all_gather_last_dim(torch.ones(3, 5)).shape == (3, 40) and not emu.ctx.distributed
