@@ -24,9 +24,11 @@ sys.path.insert(0, os.path.join(ROOT, "traffic_generator"))
 import analyze  # noqa: E402
 
 
-def wait_health(url, timeout):
+def wait_health(url, timeout, server=None):
     t0 = time.time()
     while time.time() - t0 < timeout:
+        if server is not None and server.poll() is not None:
+            raise RuntimeError(f"the server exited with code {server.returncode} before it became healthy")
         try:
             with urllib.request.urlopen(url + "/health", timeout=2) as r:
                 if r.status == 200:
@@ -49,6 +51,9 @@ def main():
     ap.add_argument("--slo", default="llama3-8b-relaxed")
     ap.add_argument("--out-dir", default=os.path.join(ROOT, "gpurun_out", "replay"))
     ap.add_argument("--router-replicas", type=int, default=0, help="put the DP router in front of N replicas")
+    ap.add_argument("--tp", type=int, default=1, help="tensor-parallel degree of the served replica (api_server --tp)")
+    ap.add_argument("--ep", type=int, default=1, help="expert-parallel degree (MoE models; 1 or tp)")
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"])
     ap.add_argument("--server-args", default="", help="extra args for api_server, space separated")
     a = ap.parse_args()
     a.out_dir = os.path.abspath(a.out_dir)
@@ -63,7 +68,7 @@ def main():
         df.to_csv(trace_path, index=False)
 
     base = f"http://127.0.0.1:{a.port}"
-    extra = a.server_args.split() if a.server_args else []
+    extra = ["--tp", str(a.tp), "--ep", str(a.ep), "--kv-dtype", a.kv_dtype] + (a.server_args.split() if a.server_args else [])
     if a.router_replicas:
         cmd = [sys.executable, "-m", "dli_amd.router.router", "--spawn", str(a.router_replicas), "--port", str(a.port),
                "--host", "127.0.0.1", "--model", a.model, "--device", a.device] + (["--cpu"] if a.device == "cpu" else []) + extra
@@ -73,7 +78,7 @@ def main():
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     server = subprocess.Popen(cmd, env=env, cwd=ROOT)
     try:
-        wait_health(base, 900)
+        wait_health(base, 900, server)
         log_path = os.path.join(a.out_dir, "log.json")
         side_path = os.path.join(a.out_dir, "sidecar.json")
         t0 = time.time()
@@ -88,7 +93,7 @@ def main():
         ttft, tpot = analyze.SLOS[a.slo]
         summary = analyze.summarize(metrics, n_out, slo_ttft=ttft, slo_tpot=tpot)
         summary.update(model=a.model, qps_scale=a.qps_scale, max_tokens=a.max_tokens, harness_wall_s=wall,
-                       router_replicas=a.router_replicas)
+                       router_replicas=a.router_replicas, tp=a.tp, ep=a.ep, kv_dtype=a.kv_dtype)
         try:
             with urllib.request.urlopen(base + ("/router/stats" if a.router_replicas else "/stats"), timeout=5) as r:
                 summary["server_stats"] = json.loads(r.read())
@@ -96,7 +101,14 @@ def main():
             pass
         with open(os.path.join(a.out_dir, "summary.json"), "w") as fh:
             json.dump(summary, fh, indent=1)
-        print(json.dumps({k: v for k, v in summary.items() if k != "server_stats"}))
+        st = summary.get("server_stats") or {}
+        brief = {k: v for k, v in summary.items() if k != "server_stats"}
+        if "comm" in st:                                     # TP replica: what it ran on, like the bench line says
+            brief["comm"] = {k: st["comm"].get(k) for k in ("tp", "ep", "device_backend", "custom_ar_enabled", "pipelined_steps",
+                                                            "rccl_ranks_joined", "ranks_share_gpu")}
+            brief["selftest"] = st.get("selftest")
+            brief["graph_steps"], brief["eager_steps"] = st.get("graph_steps"), st.get("eager_steps")
+        print(json.dumps(brief))
     finally:
         server.terminate()
         try:

@@ -59,6 +59,20 @@ class _QueueChannel:
         return self.rx.get()
 
 
+def _comm_info(engine) -> dict:
+    """What the TP group of this engine runs on — the same fields the bench JSON line carries."""
+    from ..runtime.tp_launcher import job_info
+    ctx = engine.ctx
+    info = {"tp": ctx.tp_size, "ep": ctx.ep_size, "device_backend": ctx.device_backend,
+            "custom_ar_enabled": bool(ctx.custom_ar is not None and ctx.custom_ar.enabled),
+            "pipelined_steps": bool(engine.async_scheduling), "per_kind": dict(ctx.comm)}
+    j = job_info()
+    for k in ("control_backend", "rccl_ranks_joined", "device_ids", "ranks_share_gpu", "probe", "tp_group_tuning"):
+        if k in j:
+            info[k] = j[k]
+    return info
+
+
 def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
     """Runs until ("shutdown",): drain commands → one engine step → ship that step's tokens."""
     def stats():
@@ -66,6 +80,8 @@ def engine_core_loop(engine, chan, idle_wait: float = 0.02) -> None:
         d.update(outstanding_tokens=engine.outstanding_tokens(), num_running=engine.num_running,
                  num_waiting=engine.num_waiting, kv_cache_tokens=engine.runner.kv_cache_tokens,
                  graph_steps=engine.runner.stats["graph_steps"], eager_steps=engine.runner.stats["eager_steps"],
+                 mixed_graph_steps=engine.runner.stats["mixed_graph_steps"], ar_fallbacks=engine.runner.stats["ar_fallbacks"],
+                 selftest=engine.runner.selftest, comm=_comm_info(engine),
                  prometheus=engine.metrics.render_prometheus())
         return d
 

@@ -93,13 +93,19 @@ class RowParallelLinear(nn.Module):
 
     For prefill-sized inputs on a GPU the GEMM and the all-reduce are *pipelined*: the rows are cut
     into chunks, chunk i is reduced over xGMI on a side stream while the GEMM of chunk i+1 runs on the
-    compute stream (north-star item 3: "all-reduce over xGMI overlapped with the GEMMs").  Decode-sized
-    inputs take the single-kernel custom all-reduce inside the hipGraph instead (latency-bound, nothing
-    to overlap with)."""
+    compute stream (north-star item 3: "all-reduce over xGMI overlapped with the GEMMs").  The reduction of a
+    chunk is whichever stream-ordered collective the group has: the custom IPC kernel (chunks up to its staging
+    size; with a launch capped at ``OVERLAP_AR_BLOCKS`` workgroups so that the GEMM keeps most of the CUs) or RCCL
+    (``nccl`` device group, chunks past the custom kernel's crossover) — so the pipeline also runs, and is tested, when
+    the ranks share one GPU with gloo as the library backend.  Both are plain stream work: inside a hipGraph capture
+    the side stream forks from and joins the capturing stream, and the overlap is part of the captured step.
+    Decode-sized inputs take the single-kernel all-reduce (latency-bound, nothing to overlap with)."""
 
     OVERLAP_MIN_ROWS = int(__import__('os').environ.get('DLI_OVERLAP_MIN_ROWS', '1024'))
-    OVERLAP_CHUNKS = 4
+    OVERLAP_CHUNKS = int(__import__('os').environ.get('DLI_OVERLAP_CHUNKS', '4'))
+    OVERLAP_AR_BLOCKS = int(__import__('os').environ.get('DLI_OVERLAP_AR_BLOCKS', '64'))
     OVERLAP_OK = True          # cleared by ModelRunner.startup_selftest when the pipeline disagrees with the plain path
+    overlap_calls = 0          # forward passes that took the pipeline (tests assert the path was taken)
 
     def __init__(self, in_features: int, out_features: int, ctx: ParallelContext, dtype, device, bias: bool = False,
                  reduce: bool = True):
@@ -113,29 +119,44 @@ class RowParallelLinear(nn.Module):
         # the bias must be added once, not tp times: only rank 0 adds it before the reduction
         b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
         if (self.reduce and self.OVERLAP_OK and self.ctx.distributed and x.is_cuda and x.dim() == 2
-                and x.shape[0] >= self.OVERLAP_MIN_ROWS and self._stream_ordered_backend() and not torch.cuda.is_current_stream_capturing()):
+                and x.shape[0] >= self.OVERLAP_MIN_ROWS and self.overlap_capable()):
             return self._forward_overlapped(x, b)
         y = ops.linear(x, self.weight.data, b)
         return self.ctx.all_reduce(y) if self.reduce else y
 
-    def _stream_ordered_backend(self) -> bool:
-        """The pipeline relies on stream-ordered collectives (RCCL).  gloo moves CUDA tensors through host
-        buffers on its own threads/streams; in the single-GPU rehearsal mode (DLI_TP_SHARE_GPU=1) that path
-        produced rank-divergent sums under skew, so it stays on the plain GEMM → all-reduce sequence."""
+    def _library_is_stream_ordered(self) -> bool:
+        """RCCL is; gloo moves CUDA tensors through host buffers on its own threads (rank-divergent sums under skew in
+        the single-GPU rehearsal mode), so a gloo group pipelines through the custom kernels only."""
         if not hasattr(self, "_nccl"):
             import torch.distributed as dist
-            self._nccl = dist.get_backend(self.ctx.group) == "nccl"
+            self._nccl = self.ctx.group is not None and dist.get_backend(self.ctx.group) == "nccl"
         return self._nccl
+
+    def overlap_capable(self) -> bool:
+        ar = self.ctx.custom_ar
+        return self.ctx.distributed and (self._library_is_stream_ordered() or (ar is not None and ar.enabled))
+
+    def _chunk_rows(self, T: int, row_bytes: int) -> int:
+        step = (T + self.OVERLAP_CHUNKS - 1) // self.OVERLAP_CHUNKS
+        step = (step + 255) // 256 * 256                       # whole MFMA macro-tiles per chunk
+        ar = self.ctx.custom_ar
+        if ar is not None and ar.enabled and not self._library_is_stream_ordered():
+            step = min(step, max(ar.max_bytes // row_bytes // 256 * 256, 256))   # every chunk must fit the IPC staging buffer
+        return step
 
     def _forward_overlapped(self, x, b):
         import torch.distributed as dist
+        type(self).overlap_calls += 1
         T = x.shape[0]
-        n = self.OVERLAP_CHUNKS
-        step = (T + n - 1) // n
-        step = (step + 255) // 256 * 256                       # whole MFMA macro-tiles per chunk
-        y = torch.empty(T, self.weight.data.shape[0], dtype=x.dtype, device=x.device)
+        N = self.weight.data.shape[0]
+        step = self._chunk_rows(T, N * x.element_size())
+        y = torch.empty(T, N, dtype=x.dtype, device=x.device)      # partial sums (GEMM output)
+        ar = self.ctx.custom_ar
+        use_custom = ar is not None and ar.enabled
+        z = torch.empty_like(y) if use_custom else y               # the custom kernel reduces out of place
         main = torch.cuda.current_stream()
         side = _comm_stream(x.device)
+        c = self.ctx.comm
         done = []
         for lo in range(0, T, step):
             hi = min(lo + step, T)
@@ -143,18 +164,25 @@ class RowParallelLinear(nn.Module):
                 torch.addmm(b, x[lo:hi], self.weight.data.t(), out=y[lo:hi])
             ready = torch.cuda.Event()
             ready.record(main)
+            nbytes = (hi - lo) * N * y.element_size()
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                c = self.ctx.comm
-                c["ar_lib_calls"] += 1
-                c["ar_lib_bytes"] += (hi - lo) * y.shape[1] * y.element_size()
-                dist.all_reduce(y[lo:hi], group=self.ctx.group)    # RCCL on the comm stream, GEMM i+1 meanwhile
+                if use_custom and (ar.should_use(y[lo:hi]) or not self._library_is_stream_ordered()):
+                    c["ar_custom_calls"] += 1
+                    c["ar_custom_bytes"] += nbytes
+                    ar.all_reduce(y[lo:hi], blocks=self.OVERLAP_AR_BLOCKS, out=z[lo:hi])   # IPC kernel, GEMM i+1 meanwhile
+                else:
+                    c["ar_lib_calls"] += 1
+                    c["ar_lib_bytes"] += nbytes
+                    dist.all_reduce(y[lo:hi], group=self.ctx.group)    # RCCL on the comm stream, GEMM i+1 meanwhile
+                    if z is not y:
+                        z[lo:hi].copy_(y[lo:hi])
                 ev = torch.cuda.Event()
                 ev.record(side)
                 done.append(ev)
         for ev in done:
             main.wait_event(ev)
-        return y
+        return z
 
 
 _COMM_STREAMS: dict = {}

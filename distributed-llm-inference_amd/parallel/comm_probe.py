@@ -75,7 +75,7 @@ def _probe_main(a) -> dict:
         ok = ar.self_test()
         res["custom_ar_ok"] = ok
         if ok and a.seconds > 0:
-            sizes = [s for s in (8 << 10, 32 << 10, 128 << 10, 512 << 10, 2 << 20, 8 << 20, 32 << 20) if s <= a.max_bytes]
+            sizes = [s for s in (8 << 10, 32 << 10, 128 << 10, 512 << 10, 2 << 20, 8 << 20, 32 << 20, 64 << 20) if s <= a.max_bytes]
             if a.full:
                 sizes = [8 << 10 << i for i in range(13) if (8 << 10 << i) <= a.max_bytes]
             tun = ar.tune(sizes=sizes, iters=a.iters, with_library=nccl_group is not None)
@@ -88,6 +88,7 @@ def _probe_main(a) -> dict:
                               "two_shot_us": min((c["us"] for c in two), default=None),
                               "two_shot_blocks": min(two, key=lambda c: c["us"])["blocks"] if two else None,
                               "rccl_eager_us": row.get("library_us")})
+            res["tuning_rows"] = tun["rows"]                 # the engine installs this table instead of sweeping again
             res["custom_vs_library_crossover_bytes"] = tun["use_custom_up_to_bytes"]
             res["one_shot_up_to_bytes"] = tun["one_shot_up_to_bytes"]
             res["sweep_seconds"] = tun["sweep_seconds"]
@@ -140,7 +141,7 @@ def main(argv=None) -> int:
     ap.add_argument("--seconds", type=float, default=5.0, help="0: connectivity checks only, no latency table")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--full", action="store_true", help="every power of two from 8 KB to max-bytes")
-    ap.add_argument("--max-bytes", type=int, default=32 << 20)
+    ap.add_argument("--max-bytes", type=int, default=64 << 20)
     ap.add_argument("--timeout", type=float, default=120.0)
     a = ap.parse_args(argv)
     res = _probe_main(a)
@@ -151,7 +152,7 @@ def main(argv=None) -> int:
 
 
 def probe_in_subprocess(rank: int, world: int, device: int, port: int, share_gpu: bool = False, seconds: float = 5.0,
-                        timeout: float = 150.0, full: bool = False, iters: int = 10, max_bytes: int = 32 << 20) -> dict:
+                        timeout: float = 150.0, full: bool = False, iters: int = 10, max_bytes: int = 64 << 20) -> dict:
     """Run the probe for this rank in a child process; never raises.  On a crash, a time-out or a missing result the
     returned dict has ``rccl_ok = custom_ar_ok = False`` and says why."""
     root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -25,11 +25,11 @@ import torch.distributed as dist
 
 from .. import ops
 
-_SIZES = (8 << 10, 32 << 10, 128 << 10, 512 << 10, 1 << 20, 2 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20)
+_SIZES = (8 << 10, 32 << 10, 128 << 10, 512 << 10, 1 << 20, 2 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20, 64 << 20)
 
 
 class CustomAllReduce:
-    def __init__(self, ctx, device, max_bytes: int = 32 << 20):
+    def __init__(self, ctx, device, max_bytes: int = 64 << 20):
         lib = ops.hip()
         self.lib, self.ctx, self.device, self.max_bytes = lib, ctx, device, max_bytes
         self.use_max_bytes = max_bytes                      # custom path up to here, library above (set by tune())
@@ -80,9 +80,10 @@ class CustomAllReduce:
         return self.ctx.cpu_group if self.ctx.cpu_group is not None else self.ctx.group
 
     @classmethod
-    def create(cls, ctx, device, max_bytes: int = 32 << 20, tune: bool | None = None):
+    def create(cls, ctx, device, max_bytes: int = 64 << 20, tune: bool | None = None, tuning_rows: list | None = None):
         """Returns a verified (and tuned) instance, or ``None`` (→ library collectives only) if set-up or the
-        self-test fails on any rank."""
+        self-test fails on any rank.  ``tuning_rows``: the launch-shape table a first-contact probe of the SAME group
+        already measured (``comm_probe``) — installed as is instead of sweeping a second time."""
         try:
             ar = cls(ctx, device, max_bytes)
             if not ar.self_test():
@@ -91,7 +92,9 @@ class CustomAllReduce:
                 return None
             if tune is None:
                 tune = os.environ.get("DLI_AR_TUNE", "1") != "0"
-            if tune:
+            if tuning_rows:
+                ar.install_table(ctx.broadcast_object(tuning_rows, src=0), source="probe")
+            elif tune:
                 ar.tune()
             return ar
         except Exception as e:                              # IPC unavailable, > 8 ranks, …
@@ -103,9 +106,11 @@ class CustomAllReduce:
         return (self.enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
                 and 0 < x.numel() * 2 <= self.use_max_bytes and (x.numel() * 2) % 16 == 0 and x.data_ptr() % 16 == 0)
 
-    def all_reduce(self, x: torch.Tensor, algo: int = 0, blocks: int = 0) -> torch.Tensor:
-        """Out-of-place sum over the TP group (``algo``: 0 tuned/auto, 1 one-shot, 2 two-shot)."""
-        out = torch.empty_like(x)
+    def all_reduce(self, x: torch.Tensor, algo: int = 0, blocks: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Out-of-place sum over the TP group (``algo``: 0 tuned/auto, 1 one-shot, 2 two-shot; ``blocks``: 0 tuned, else
+        a cap on the workgroups — every rank must pass the same value)."""
+        if out is None:
+            out = torch.empty_like(x)
         self.lib.ar_all_reduce(self.state, x, out, algo, blocks)
         return out
 
@@ -199,6 +204,26 @@ class CustomAllReduce:
         torch.cuda.synchronize()
         return a.elapsed_time(b) * 1e3 / iters
 
+    def _library_capturable(self) -> bool:
+        """Can every rank capture a library all-reduce in a hipGraph?  Capture only — nothing is replayed before the
+        group has voted, so a rank whose capture failed never leaves its peers waiting inside a collective."""
+        ok = True
+        try:
+            x = torch.ones(4096, dtype=torch.bfloat16, device=self.device)
+            dist.all_reduce(x, group=self.ctx.group)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            s = torch.cuda.Stream(device=self.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=s):
+                dist.all_reduce(x, group=self.ctx.group)
+            torch.cuda.synchronize()
+        except Exception:
+            ok = False
+        votes = [None] * self.world
+        dist.all_gather_object(votes, ok, group=self._cpu_group())
+        return all(votes)
+
     def tune(self, sizes=_SIZES, iters: int = 10, with_library: bool | None = None, in_graph: bool = True) -> dict:
         """Sweep (algorithm × workgroups) per message size; install the winners on every rank.
 
@@ -211,6 +236,9 @@ class CustomAllReduce:
         if with_library is None:
             with_library = dist.get_backend(self.ctx.group) == "nccl"
         timer = self._time_graph if in_graph else self._time_eager
+        lib_timer = timer
+        if with_library and in_graph and not self._library_capturable():
+            lib_timer = self._time_eager                     # agreed by the whole group: nobody replays what a peer lacks
         rows = []
         for nbytes in sizes:
             x = torch.ones(nbytes // 2, dtype=torch.bfloat16, device=self.device)
@@ -228,8 +256,13 @@ class CustomAllReduce:
                     cands.append({"algo": algo, "blocks": blocks, "us": round(us, 2)})
             row = {"bytes": nbytes, "candidates": cands}
             if with_library:
+                # the same clock for both sides: RCCL replayed inside a hipGraph like the custom kernels (an eager
+                # launch carries ≈ 10 µs of host work per call that a captured decode step does not pay); eager only
+                # where the group found that the library cannot be captured
+                fn_lib = lambda: dist.all_reduce(x, group=self.ctx.group)
                 try:
-                    row["library_us"] = round(self._time_eager(lambda: dist.all_reduce(x, group=self.ctx.group), iters), 2)
+                    row["library_us"] = round(lib_timer(fn_lib, iters), 2)
+                    row["library_timed_in_graph"] = lib_timer is self._time_graph
                 except Exception as e:                       # the sweep must never take the engine down
                     row["library_error"] = f"{type(e).__name__}: {e}"
             rows.append(row)
@@ -240,6 +273,13 @@ class CustomAllReduce:
         if any(flags):
             raise RuntimeError(f"custom all-reduce kernel timed out during the launch-shape sweep (ranks {[i for i, f in enumerate(flags) if f]})")
         rows = self.ctx.broadcast_object(rows, src=0)        # rank 0's clock decides for everyone
+        self.install_table(rows, source="sweep", timed_in_graph=in_graph, seconds=time.perf_counter() - t_begin)
+        dist.barrier(group=self._cpu_group())
+        return self.tuning
+
+    def install_table(self, rows: list, source: str = "sweep", timed_in_graph: bool = True, seconds: float = 0.0) -> dict:
+        """Per size bucket: the fastest (algorithm, workgroups); ``use_max_bytes`` = where the library starts to win on
+        every larger size.  ``rows`` must be identical on every rank of the group."""
         thr, algos, blocks = [], [], []
         use_max = self.max_bytes
         lib_wins_from = None
@@ -258,12 +298,12 @@ class CustomAllReduce:
             prev = [r["bytes"] for r in rows if r["bytes"] < lib_wins_from]
             use_max = prev[-1] if prev else 0
         one_shot_max = max([r["bytes"] for r in rows if r["best"]["algo"] == 1], default=0)
-        lib.ar_set_tuning(self.state, torch.tensor(thr, dtype=torch.int64), torch.tensor(algos, dtype=torch.int32),
-                          torch.tensor(blocks, dtype=torch.int32), int(blocks[-1]) if blocks else 64, int(one_shot_max))
+        self.lib.ar_set_tuning(self.state, torch.tensor(thr, dtype=torch.int64), torch.tensor(algos, dtype=torch.int32),
+                               torch.tensor(blocks, dtype=torch.int32), int(blocks[-1]) if blocks else 64, int(one_shot_max))
         self.use_max_bytes = use_max
-        self.tuning = {"world": self.world, "timed_in_graph": in_graph, "rows": rows, "use_custom_up_to_bytes": use_max,
-                       "one_shot_up_to_bytes": one_shot_max, "sweep_seconds": round(time.perf_counter() - t_begin, 2)}
-        dist.barrier(group=self._cpu_group())
+        self.tuning = {"world": self.world, "source": source, "timed_in_graph": timed_in_graph, "rows": rows,
+                       "use_custom_up_to_bytes": use_max, "one_shot_up_to_bytes": one_shot_max,
+                       "sweep_seconds": round(seconds, 2)}
         return self.tuning
 
     def close(self):

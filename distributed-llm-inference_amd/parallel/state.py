@@ -222,7 +222,7 @@ def init_distributed(backend: str = "auto", device: Optional[torch.device] = Non
 def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None, with_cpu_group: bool = True,
                     custom_all_reduce: bool = False, device: Optional[torch.device] = None,
                     all_groups: Optional[list] = None, device_backend: Optional[str] = None,
-                    ep_a2a_min_tokens: int = 0) -> ParallelContext:
+                    ep_a2a_min_tokens: int = 0, ar_tuning_rows: Optional[list] = None) -> ParallelContext:
     """TP group over ``ranks`` (default: the whole world).  Must be called by every rank of the world.
 
     ``all_groups``: every TP group of the job (list of rank lists, ``ranks`` among them) when the world holds several
@@ -250,7 +250,7 @@ def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None
                           ep_size=ep_size, ep_a2a_min_tokens=ep_a2a_min_tokens if ep_size > 1 else 0)
     if custom_all_reduce and device is not None and device.type == "cuda":
         from .custom_all_reduce import CustomAllReduce
-        ar = CustomAllReduce.create(ctx, device)
+        ar = CustomAllReduce.create(ctx, device, tuning_rows=ar_tuning_rows)
         # all or nothing: one rank without the fast path while its peers wait in the kernels' flag barriers is a hang
         if not ctx.all_min_int(1 if ar is not None else 0):
             if ar is not None:

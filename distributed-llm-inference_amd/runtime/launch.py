@@ -146,11 +146,21 @@ class Job:
     comm: dict = field(default_factory=dict)   # probe verdict + all-reduce table + what is in use
 
 
+def share_gpu_requested() -> bool:
+    """One switch for every launcher (bench.py, api_server --tp, the tests): ranks may share a device for a
+    functional rehearsal on a box with fewer GPUs than ranks.  (The two older names are still honoured.)"""
+    return any(os.environ.get(k) == "1" for k in ("DLI_SHARE_GPU", "DLI_BENCH_SHARE_GPU", "DLI_TP_SHARE_GPU")) \
+        or os.environ.get("DLI_BENCH_BACKEND") == "gloo"
+
+
 def bootstrap(layout: Layout, device_kind: str = "cuda", share_gpu: bool = False, custom_all_reduce: bool = True,
               probe_seconds: float = 5.0, probe_timeout: float = 150.0, ep_a2a_min_tokens: int = 0,
-              group_timeout_s: float = 900.0) -> Job:
+              group_timeout_s: float = 900.0, device_base: int = 0, force_backend: Optional[str] = None) -> Job:
     """Join the job: pick this rank's device, build the control plane, probe the device collectives in a child
-    process, build the TP context on what the probe proved.  Every rank calls this with the same arguments."""
+    process, build the TP context on what the probe proved.  Every rank calls this with the same arguments.
+    THE bootstrap of every multi-rank entry point: ``bench.py`` ranks and the TP workers of ``api_server --tp``
+    (``runtime/tp_launcher.py``) both come through here.  ``device_base``: first device of this job (a DP replica of the
+    router owns devices ``base … base + tp - 1``); ``force_backend="gloo"`` skips RCCL (CPU-style rehearsals)."""
     import torch
     import torch.distributed as dist
     from ..parallel.comm_probe import probe_in_subprocess
@@ -162,11 +172,11 @@ def bootstrap(layout: Layout, device_kind: str = "cuda", share_gpu: bool = False
         n_dev = torch.cuda.device_count()                    # does not initialise the GPU on this image
         if n_dev < 1:
             raise SystemExit("no GPU visible")
-        if n_dev < layout.world and not share_gpu:
-            raise SystemExit(f"{layout.world} ranks but {n_dev} GPU(s) visible (DLI_BENCH_SHARE_GPU=1 lets ranks "
-                             "share a device for a functional rehearsal)")
-        share_gpu = share_gpu and n_dev < layout.world
-        dev_index = layout.local_rank % n_dev
+        if n_dev < device_base + layout.world and not share_gpu:
+            raise SystemExit(f"{layout.world} ranks from device {device_base} but {n_dev} GPU(s) visible (DLI_SHARE_GPU=1 lets "
+                             "ranks share a device for a functional rehearsal)")
+        share_gpu = share_gpu and n_dev < device_base + layout.world
+        dev_index = (device_base + layout.local_rank) % n_dev
         device = torch.device("cuda", dev_index)
     else:
         dev_index, device, share_gpu = -1, torch.device("cpu"), False
@@ -199,7 +209,7 @@ def bootstrap(layout: Layout, device_kind: str = "cuda", share_gpu: bool = False
         allp = [None] * layout.world
         dist.all_gather_object(allp, mine)
         probe = dict(allp[0])
-        probe["rccl_ok"] = all(p.get("rccl_ok") for p in allp)
+        probe["rccl_ok"] = all(p.get("rccl_ok") for p in allp) and force_backend in (None, "nccl")
         probe["custom_ar_ok"] = all(p.get("custom_ar_ok") for p in allp)
         probe["rccl_ranks_joined"] = layout.world if probe["rccl_ok"] else 0
         errs = {str(i): {k: v for k, v in p.items() if k.endswith("error")} for i, p in enumerate(allp)}
@@ -223,17 +233,21 @@ def bootstrap(layout: Layout, device_kind: str = "cuda", share_gpu: bool = False
             backend, want_custom = "gloo", False
         my_group = layout.groups[layout.replica]
         try:
+            # the probe child of TP rank 0 of THIS replica swept the launch shapes of the same peers: its table is
+            # installed instead of a second sweep (a world-wide probe over several replicas measured other group sizes)
+            rows = probe.get("tuning_rows") if (layout.dp == 1 and os.environ.get("DLI_AR_RETUNE") != "1") else None
             ctx = make_tp_context(layout.tp, ep_size=layout.ep, ranks=my_group, all_groups=layout.groups,
                                   custom_all_reduce=want_custom, device=device, device_backend=backend,
-                                  ep_a2a_min_tokens=ep_a2a_min_tokens)
+                                  ep_a2a_min_tokens=ep_a2a_min_tokens, ar_tuning_rows=rows)
         except Exception as e:
             raise SystemExit(f"rank {layout.rank}: could not build the TP group over {backend}: {type(e).__name__}: {e}")
         job.ctx = ctx
+        probe.pop("tuning_rows", None)                       # installed (or superseded by the group's own sweep)
         comm["device_backend"] = {"nccl": "rccl"}.get(backend, backend)
         comm["custom_ar_enabled"] = bool(ctx.custom_ar is not None and ctx.custom_ar.enabled)
         if ctx.custom_ar is not None and ctx.custom_ar.tuning:
             t = ctx.custom_ar.tuning
-            comm["tp_group_tuning"] = {"use_custom_up_to_bytes": t["use_custom_up_to_bytes"],
+            comm["tp_group_tuning"] = {"source": t.get("source"), "use_custom_up_to_bytes": t["use_custom_up_to_bytes"],
                                        "one_shot_up_to_bytes": t["one_shot_up_to_bytes"],
                                        "sweep_seconds": t["sweep_seconds"],
                                        "best": [{"bytes": r["bytes"], **r["best"], "library_us": r.get("library_us")}

@@ -103,6 +103,11 @@ class ModelRunner:
         logits = c.sched.max_num_seqs * m.vocab_size * 8
         reserve = max(3 * (act + logits), 4 << 30) + (2 << 30)       # + graph pools
         budget = free - (total * (1.0 - c.cache.gpu_memory_utilization)) - reserve
+        n_dev = max(torch.cuda.device_count(), 1)
+        if self.ctx.distributed and n_dev < self.ctx.tp_size:
+            # rehearsal mode: several ranks of the group live on this device and size their caches at the same time
+            sharing = (self.ctx.tp_size + n_dev - 1) // n_dev
+            budget = (budget - (sharing - 1) * reserve) / sharing
         n = int(budget // per_block)
         if n < self.max_blocks_per_seq:
             raise RuntimeError(f"not enough HBM for the KV cache: {budget / 2**30:.1f} GiB left after weights")
@@ -244,9 +249,6 @@ class ModelRunner:
     def _sample_rows(self, h_rows, S):
         dv = self.dv
         logits = self.model.compute_logits(h_rows)
-        if _DUMP_LOGITS and self.ctx.is_driver and not torch.cuda.is_current_stream_capturing() and not self._dumped:
-            self._dumped = True                              # debug aid: first sampled row of the first eager step
-            torch.save(logits[0].float().cpu(), _DUMP_LOGITS)
         if _DEBUG_BOUNDS and not (self.on_gpu and torch.cuda.is_current_stream_capturing()):
             # the sampler maps a NaN row to token 0 instead of an out-of-range id; in debug mode the NaN itself is the error
             assert bool(torch.isfinite(logits[: max(S, 1)].float()).all()), "non-finite logits"
@@ -446,7 +448,7 @@ class ModelRunner:
         if bucket:
             if bucket not in self.graphs:
                 self.capture_graph(bucket)
-            self._replay(bucket)
+            self._maybe_dump(self._replay(bucket))
             self.stats["graph_steps"] += 1
             return self._fetch(B)
         if tb:
@@ -456,12 +458,12 @@ class ModelRunner:
             if S:
                 if ("h", sb) not in self.graphs:
                     self.capture_head_graph(sb)
-                self._replay(("h", sb))
+                self._maybe_dump(self._replay(("h", sb)))
             self.stats["graph_steps"] += 1
             self.stats["mixed_graph_steps"] += 1
             return self._fetch(S)
         meta = self._meta(B, T, nd, n_items, n_reds, n_tiles)
-        self._forward_sample(T, S, meta)
+        self._maybe_dump(self._forward_sample(T, S, meta))
         self.stats["eager_steps"] += 1
         return self._fetch(S)
 
@@ -470,6 +472,14 @@ class ModelRunner:
         g[0].replay()
         for k, v in g[3].items():                            # collectives inside the graph, counted at capture
             self.ctx.comm[k] += v
+        return g[2]
+
+    def _maybe_dump(self, logits):
+        """Debug aid (DLI_DUMP_LOGITS=<file>): logits of the first sampled row of the first SERVED step — eager or
+        replayed (the graphs keep their logits buffer) — on the driver; warm-up and capture runs never get here."""
+        if _DUMP_LOGITS and not self._dumped and logits is not None and self.ctx.is_driver:
+            self._dumped = True
+            torch.save(logits[0].float().cpu(), _DUMP_LOGITS)
 
     def _check_bounds(self, B: int, T: int, n_cow: int) -> None:
         """``DLI_DEBUG_BOUNDS=1``: before any kernel of the step runs, read the step's metadata back
@@ -581,7 +591,9 @@ class ModelRunner:
         items, reds = self._decode_caps(bucket)
         meta = self._meta(bucket, bucket, bucket, items, reds, 0, counts_on_device=True)
         g, logits, comm = self._capture(bucket, lambda: self._forward_sample(bucket, bucket, meta))
-        self.graphs[bucket] = (g, meta, logits, comm)        # `logits`: the graph's own output buffer (self-test reads it)
+        # `logits`: the graph's own output buffer (the self-test and the debug dump read it).  Only small buckets keep
+        # theirs alive: a [2048, 128 k] buffer per graph would pin gigabytes of the shared pool that later captures reuse
+        self.graphs[bucket] = (g, meta, logits if (bucket <= 64 or _DUMP_LOGITS) else None, comm)
         return g
 
     def capture_mixed_graph(self, tb: int):
@@ -596,13 +608,13 @@ class ModelRunner:
             torch.index_select(h, 0, dv["last"][:rows], out=self.h_last[:rows])
             return h
         g, h, comm = self._capture(("m", tb), run)
-        self.graphs[("m", tb)] = (g, meta, h, comm)
+        self.graphs[("m", tb)] = (g, meta, None, comm)
         return g
 
     def capture_head_graph(self, sb: int):
         """LM head + sampler over the first ``sb`` rows of ``h_last``."""
         g, logits, comm = self._capture(("h", sb), lambda: self._sample_rows(self.h_last[:sb], sb))
-        self.graphs[("h", sb)] = (g, None, logits, comm)
+        self.graphs[("h", sb)] = (g, None, logits if (sb <= 64 or _DUMP_LOGITS) else None, comm)
         return g
 
     # ------------------------------------------------------------------ fp8 KV calibration
@@ -830,8 +842,8 @@ class ModelRunner:
         if self.ctx.distributed:
             from ..models.layers import RowParallelLinear
             layer = next((m for m in self.model.modules() if isinstance(m, RowParallelLinear) and m.reduce), None)
-            if layer is None or not layer._stream_ordered_backend():
-                res["overlapped_row_parallel"] = {"ok": None, "skipped": f"device backend {self.ctx.device_backend}"}
+            if layer is None or not layer.overlap_capable():
+                res["overlapped_row_parallel"] = {"ok": None, "skipped": f"device backend {self.ctx.device_backend}, no custom all-reduce"}
                 RowParallelLinear.OVERLAP_OK = False
             else:
                 try:
@@ -844,7 +856,11 @@ class ModelRunner:
                     diff = float((want - got).abs().max())
                     scale = float(want.abs().max())
                     ok = bool(diff == diff and diff <= 3e-2 * scale + 1e-3)
-                    res["overlapped_row_parallel"] = {"max_abs_diff": round(diff, 6), "scale": round(scale, 4)}
+                    ar = self.ctx.custom_ar
+                    res["overlapped_row_parallel"] = {"max_abs_diff": round(diff, 6), "scale": round(scale, 4), "rows": rows,
+                                                      "chunk_rows": layer._chunk_rows(rows, want.shape[1] * 2),
+                                                      "reduced_by": "custom IPC kernel on the side stream"
+                                                      if (ar is not None and ar.enabled) else "RCCL on the side stream"}
                 except Exception as e:
                     ok = False
                     res["overlapped_row_parallel"] = {"error": f"{type(e).__name__}: {e}"}

@@ -17,7 +17,7 @@ from typing import Optional
 import torch
 
 from ..config import EngineConfig
-from ..parallel.state import SINGLE, ParallelContext, init_distributed, make_tp_context
+from ..parallel.state import SINGLE, ParallelContext
 
 
 def _free_port() -> int:
@@ -26,26 +26,39 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _device_for(cfg: EngineConfig, rank: int, base_index: int) -> torch.device:
-    use_gpu = cfg.device == "cuda" or (cfg.device == "auto" and torch.cuda.is_available())
-    if use_gpu:
-        # DLI_TP_SHARE_GPU=1: every rank on the same device (single-GPU rehearsal of the TP path, gloo backend)
-        idx = base_index if os.environ.get("DLI_TP_SHARE_GPU") == "1" else base_index + rank
-        torch.cuda.set_device(idx)
-        return torch.device("cuda", idx)
-    return torch.device("cpu")
+_job = None            # this process's launch.Job (what /stats reports: backend, custom all-reduce, probe verdict)
+
+
+def job_info() -> dict:
+    """Communication set-up of this process's TP group, as ``bench.py`` prints it (empty for tp = 1)."""
+    if _job is None:
+        return {}
+    c = dict(_job.comm)
+    probe = dict(c.get("probe") or {})
+    probe.pop("all_reduce_table", None)
+    c["probe"] = probe
+    return c
 
 
 def _join_group(cfg: EngineConfig, rank: int, world: int, port: int, base_index: int):
+    """Every TP rank of a server — the engine-core process as rank 0, the spawned workers as ranks 1 … — joins through
+    ``launch.bootstrap``: the one bootstrap of the code base (gloo control plane, first-contact probe of RCCL and the
+    custom IPC collectives in a throw-away child, RCCL → gloo + custom-kernel fall-back, all-or-nothing custom
+    all-reduce, launch-shape table from the probe).  ``bench.py`` ranks take the same path."""
+    global _job
+    from . import launch
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       LOCAL_RANK=str(rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    device = _device_for(cfg, rank, base_index)
-    init_distributed(cfg.parallel.backend, device)
-    ctx = make_tp_context(world, ep_size=cfg.parallel.ep if cfg.parallel.ep > 1 else 1,
-                          custom_all_reduce=cfg.parallel.custom_all_reduce, device=device,
-                          ep_a2a_min_tokens=cfg.parallel.ep_a2a_min_tokens)
-    return ctx, device
+    use_gpu = cfg.device == "cuda" or (cfg.device == "auto" and torch.cuda.device_count() > 0)
+    layout = launch.Layout(rank, world, rank, tp=world, ep=cfg.parallel.ep if cfg.parallel.ep > 1 else 1)
+    probe_s = float(os.environ.get("DLI_COMM_PROBE_SECONDS", "3"))
+    _job = launch.bootstrap(layout, device_kind="cuda" if use_gpu else "cpu", share_gpu=launch.share_gpu_requested(),
+                            custom_all_reduce=cfg.parallel.custom_all_reduce and os.environ.get("DLI_NO_CUSTOM_AR") != "1",
+                            probe_seconds=probe_s, ep_a2a_min_tokens=cfg.parallel.ep_a2a_min_tokens,
+                            device_base=base_index,
+                            force_backend="gloo" if cfg.parallel.backend == "gloo" else None)
+    return _job.ctx, _job.device
 
 
 def _die_with_parent(parent_pid: int) -> None:
@@ -113,6 +126,11 @@ def maybe_launch_tp(cfg: EngineConfig, base_index: int = 0) -> Optional[Parallel
         _children.append(p)
     ctx, _device = _join_group(cfg, 0, tp, port, base_index)
     return ctx
+
+
+def current_device():
+    """Device this process's rank was given by the bootstrap (None before / without one)."""
+    return None if _job is None else _job.device
 
 
 def check_children():

@@ -338,6 +338,8 @@ def engine_config_from_args(a) -> EngineConfig:
     overrides = {}
     if a.max_position:
         overrides["max_position"] = a.max_position
+    if getattr(a, "num_layers", None):
+        overrides["num_layers"] = a.num_layers
     return EngineConfig(
         model=get_model_config(a.model, **overrides),
         cache=CacheConfig(kv_dtype=a.kv_dtype, num_blocks=a.num_kv_blocks, gpu_memory_utilization=a.gpu_memory_utilization,
@@ -368,6 +370,7 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--max-num-batched-tokens", type=int, default=4096)
     ap.add_argument("--max-model-len", type=int, default=4096)
     ap.add_argument("--max-position", type=int, default=None)
+    ap.add_argument("--num-layers", type=int, default=None, help="override the layer count (rehearsals of big shapes)")
     ap.add_argument("--prefill-chunk", type=int, default=2048)
     ap.add_argument("--ttft-slo", type=float, default=None,
                     help="seconds; waiting requests already past this time-to-first-token deadline yield to fresher ones")

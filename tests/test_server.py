@@ -5,6 +5,7 @@ import asyncio
 import json
 import os
 import re
+import sys
 
 import aiohttp
 import pytest
@@ -235,3 +236,35 @@ def test_openai_n_choices_share_one_prefill():
                 st = await r.json()
             assert st["num_running"] == 0 and st["pending_first_token"] == 0
     with_server(body, mode="thread")
+
+
+def _replay_http(tmp_path, extra, timeout=600, env_extra=None):
+    """benchmarks/replay_http.py: api_server (own process, engine core + TP workers in further processes) ← the preserved
+    harness run as a script from its directory (contract I1) → log.json + summary."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out_dir = str(tmp_path / "replay")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "benchmarks", "replay_http.py"), "--port", str(port), "--trace",
+                        "../data/trace1.csv", "--max-trace", "6", "--qps-scale", "20", "--max-tokens", "8", "--out-dir", out_dir]
+                       + extra, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    brief = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    return brief, open(os.path.join(out_dir, "log.json")).read()
+
+
+def test_http_replay_against_a_tp2_server_goes_through_the_one_bootstrap(tmp_path):
+    """`api_server --tp 2` joins its ranks through `launch.bootstrap` (here: CPU, gloo), the harness
+    replays trace1.csv over HTTP against it, log.json keeps the reference's byte pattern and /stats says what the
+    group runs on — the same fields as the bench JSON line."""
+    brief, log_text = _replay_http(tmp_path, ["--model", "tiny-llama", "--device", "cpu", "--tp", "2"])
+    assert brief["success"] == 6 and brief["tp"] == 2
+    assert brief["comm"]["tp"] == 2 and brief["comm"]["device_backend"] == "gloo" and brief["comm"]["custom_ar_enabled"] is False
+    num = r"-?\d+(?:\.\d+)?(?:e-?\d+)?"
+    ref = "/root/reference/logs/log.json"
+    if os.path.exists(ref):
+        assert re.sub(num, "N", log_text) == re.sub(num, "N", open(ref).read())

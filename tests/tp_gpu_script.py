@@ -26,9 +26,15 @@ def main():
     ctx = maybe_launch_tp(cfg)
     eng = LLMEngine(cfg, ctx)
     eng.warmup()
+    from dli_amd.models.layers import RowParallelLinear
+    warm_calls = RowParallelLinear.overlap_calls             # the start-up self-test and the graph captures
     out = eng.generate(None, SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True), prompt_ids=prompts)
+    from dli_amd.runtime.tp_launcher import job_info
     info = {"greedy": out, "graph_steps": eng.runner.stats["graph_steps"],
-            "custom_ar": bool(ctx is not None and ctx.custom_ar is not None)}
+            "mixed_graph_steps": eng.runner.stats["mixed_graph_steps"], "eager_steps": eng.runner.stats["eager_steps"],
+            "custom_ar": bool(ctx is not None and ctx.custom_ar is not None),
+            "overlap_calls": RowParallelLinear.overlap_calls - warm_calls, "overlap_calls_at_warmup": warm_calls, "selftest": eng.runner.selftest,
+            "device_backend": job_info().get("device_backend"), "tuning_source": (job_info().get("tp_group_tuning") or {}).get("source")}
     eng.shutdown()
     join_children()
     print("RESULT " + json.dumps(info))
