@@ -263,7 +263,7 @@ def main():
     def note(msg):
         if layout.rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
-    share = os.environ.get("DLI_BENCH_SHARE_GPU") == "1" or os.environ.get("DLI_BENCH_BACKEND") == "gloo"
+    share = launch.share_gpu_requested()
     on_gpu = args.device == "cuda"
     job = launch.bootstrap(layout, device_kind=args.device, share_gpu=share, custom_all_reduce=not args.no_custom_ar,
                            probe_seconds=-1.0 if args.no_comm_probe else args.probe_seconds,

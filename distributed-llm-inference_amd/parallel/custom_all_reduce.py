@@ -35,6 +35,13 @@ class CustomAllReduce:
         self.use_max_bytes = max_bytes                      # custom path up to here, library above (set by tune())
         self.world, self.rank = ctx.tp_size, ctx.tp_rank
         self.tuning: dict = {}
+        # Workgroups one call may launch.  The kernels spin until the same block of every peer has arrived, so all
+        # peers' blocks must be able to be resident at once: trivially true with one GPU per rank; with several ranks
+        # on ONE device (rehearsals) world × blocks workgroups of 512 threads share its 1024 slots with the GEMMs —
+        # past about half of them a late rank's kernel cannot be scheduled and everybody times out waiting for it.
+        n_dev = max(torch.cuda.device_count(), 1)
+        sharing = (self.world + n_dev - 1) // n_dev if n_dev < self.world else 1
+        self.block_cap = int(lib.ar_max_blocks()) if sharing == 1 else max(8, min(int(lib.ar_max_blocks()), 512 // sharing // 2))
         torch.cuda.set_device(device)
         group = self._cpu_group()
         # Set-up is collective, so a failure on one rank must surface on every rank at the same exchange: each phase
@@ -111,7 +118,7 @@ class CustomAllReduce:
         a cap on the workgroups — every rank must pass the same value)."""
         if out is None:
             out = torch.empty_like(x)
-        self.lib.ar_all_reduce(self.state, x, out, algo, blocks)
+        self.lib.ar_all_reduce(self.state, x, out, algo, min(blocks, self.block_cap) if blocks else 0)
         return out
 
     def all_gather(self, x: torch.Tensor) -> torch.Tensor:
@@ -231,7 +238,7 @@ class CustomAllReduce:
         decided from TP rank 0's timings and broadcast, so the groups' launch shapes can never diverge."""
         t_begin = time.perf_counter()
         lib = self.lib
-        max_blocks = int(lib.ar_max_blocks())
+        max_blocks = self.block_cap
         sizes = [s for s in sizes if s <= self.max_bytes]
         if with_library is None:
             with_library = dist.get_backend(self.ctx.group) == "nccl"
@@ -298,8 +305,10 @@ class CustomAllReduce:
             prev = [r["bytes"] for r in rows if r["bytes"] < lib_wins_from]
             use_max = prev[-1] if prev else 0
         one_shot_max = max([r["bytes"] for r in rows if r["best"]["algo"] == 1], default=0)
+        blocks = [min(b, self.block_cap) for b in blocks]
         self.lib.ar_set_tuning(self.state, torch.tensor(thr, dtype=torch.int64), torch.tensor(algos, dtype=torch.int32),
-                               torch.tensor(blocks, dtype=torch.int32), int(blocks[-1]) if blocks else 64, int(one_shot_max))
+                               torch.tensor(blocks, dtype=torch.int32), min(int(blocks[-1]) if blocks else 64, self.block_cap),
+                               int(one_shot_max))
         self.use_max_bytes = use_max
         self.tuning = {"world": self.world, "source": source, "timed_in_graph": timed_in_graph, "rows": rows,
                        "use_custom_up_to_bytes": use_max, "one_shot_up_to_bytes": one_shot_max,

@@ -778,8 +778,8 @@ class ModelRunner:
         """Check the fast paths that change numerics-relevant execution against their plain counterparts, once, on
         every rank of the group; a path that fails (or raises) is switched off for the life of the engine and the
         reason is kept in ``self.selftest`` (bench.py prints it).  Covered: a captured decode hipGraph and a captured
-        mixed (prefill + decode) body + head graph pair against the same steps run eagerly (logit-level), and the
-        GEMM/all-reduce pipeline of ``RowParallelLinear`` against GEMM → all-reduce."""
+        mixed (prefill + decode) body + head graph pair against the same steps run eagerly (logit-level).  (The
+        GEMM/all-reduce pipeline of ``RowParallelLinear`` is checked earlier, by ``selftest_overlap``.)"""
         res = self.selftest
         if not self.on_gpu:
             return res
@@ -838,7 +838,15 @@ class ModelRunner:
                     del self.graphs[k]
                 print(f"[dli_amd] mixed-step hipGraphs disabled by the start-up self-test: {res['mixed_graph_vs_eager']}",
                       flush=True)
-        # --- overlapped row-parallel linear vs plain
+        return res
+
+    @torch.inference_mode()
+    def selftest_overlap(self) -> dict:
+        """GEMM / all-reduce pipeline of ``RowParallelLinear`` against GEMM → all-reduce, then the timing gate.  Runs
+        BEFORE the graphs are captured: the captured steps hold whichever path this leaves switched on."""
+        res = self.selftest
+        if not self.on_gpu:
+            return res
         if self.ctx.distributed:
             from ..models.layers import RowParallelLinear
             layer = next((m for m in self.model.modules() if isinstance(m, RowParallelLinear) and m.reduce), None)
@@ -848,7 +856,7 @@ class ModelRunner:
             else:
                 try:
                     g = torch.Generator(device=self.device).manual_seed(4321 + self.ctx.tp_rank)
-                    rows = max(RowParallelLinear.OVERLAP_MIN_ROWS, 1024)
+                    rows = min(max(RowParallelLinear.OVERLAP_MIN_ROWS, 2048), max(self.max_T, RowParallelLinear.OVERLAP_MIN_ROWS))
                     x = (torch.randn(rows, layer.weight.data.shape[1], generator=g, device=self.device) * 0.5).to(self.dtype)
                     want = self.ctx.all_reduce(ops.linear(x, layer.weight.data)).float()
                     got = layer._forward_overlapped(x, None).float()
@@ -870,7 +878,59 @@ class ModelRunner:
                 if not ok:
                     print(f"[dli_amd] GEMM/all-reduce overlap disabled by the start-up self-test: "
                           f"{res['overlapped_row_parallel']}", flush=True)
+                elif os.environ.get("DLI_OVERLAP_FORCE") != "1":
+                    self._gate_overlap_by_time(layer, x, res["overlapped_row_parallel"])
         return res
+
+    def _gate_overlap_by_time(self, layer, x, rec: dict) -> None:
+        """Measured, not guessed: the pipeline stays on only where it beats the plain GEMM → all-reduce sequence on THIS
+        system (two chunk counts tried; TP rank 0's clock decides for the group).  With every rank on its own GPU the
+        reduction hides behind the next chunk's GEMM; with ranks sharing one GPU (rehearsals) there is no link time to
+        hide and the co-resident kernels only take CUs from each other (profiles/overlap_ab_r3i.jsonl) — the same code
+        then switches itself off.  ``DLI_OVERLAP_FORCE=1`` skips the gate (tests of the path itself)."""
+        from ..models.layers import RowParallelLinear
+
+        def timed(fn, iters=5):
+            fn()
+            torch.cuda.synchronize()
+            self.ctx.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / iters
+
+        try:
+            # one layer per distinct shard shape (attention output and MLP down projection): the verdict is on their sum
+            layers, seen = [], set()
+            for m in self.model.modules():
+                if isinstance(m, RowParallelLinear) and m.reduce and tuple(m.weight.data.shape) not in seen:
+                    seen.add(tuple(m.weight.data.shape))
+                    layers.append((m, torch.randn(x.shape[0], m.weight.data.shape[1], device=self.device).to(self.dtype)))
+            plain = sum(timed(lambda: self.ctx.all_reduce(ops.linear(xi, m.weight.data))) for m, xi in layers)
+            piped = {}
+            for chunks in (2, 4):
+                RowParallelLinear.OVERLAP_CHUNKS = chunks
+                piped[chunks] = sum(timed(lambda: m._forward_overlapped(xi, None)) for m, xi in layers)
+            verdict = self.ctx.broadcast_object((plain, piped), src=0)
+        except Exception as e:
+            verdict = None
+            rec["timing_error"] = f"{type(e).__name__}: {e}"
+        if not self._vote(verdict is not None):
+            RowParallelLinear.OVERLAP_OK = False
+            rec["enabled"] = False
+            return
+        plain, piped = verdict
+        best = min(piped, key=piped.get)
+        RowParallelLinear.OVERLAP_CHUNKS = best
+        RowParallelLinear.OVERLAP_OK = bool(piped[best] < 0.97 * plain)
+        rec.update(plain_us=round(plain, 1), pipelined_us={str(k): round(v, 1) for k, v in piped.items()}, chunks=best,
+                   enabled=RowParallelLinear.OVERLAP_OK)
+        if not RowParallelLinear.OVERLAP_OK:
+            print(f"[dli_amd] GEMM/all-reduce overlap verified but not faster here ({piped[best]:.0f} µs against "
+                  f"{plain:.0f} µs plain at {x.shape[0]} rows): off", flush=True)
 
     def capture_all(self, buckets=None, mixed=None):
         """Pre-capture the decode graphs, then the mixed-step body graphs and the head graphs (largest first so that the
