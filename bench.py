@@ -57,7 +57,7 @@ SLOS = {
     "mixtral-8x7b": {"relaxed": (2.0, 0.200), "interactive": (0.5, 0.040)},
 }
 # default offered load per replica (requests/s), close to the measured sustainable rate of one replica
-DEFAULT_QPS = {"llama3-8b": 68.0, "llama3-70b": 6.0, "mixtral-8x7b": 40.0}
+DEFAULT_QPS = {"llama3-8b": 70.0, "llama3-70b": 6.0, "mixtral-8x7b": 40.0}
 
 
 def parse(argv=None):
@@ -92,6 +92,7 @@ def parse(argv=None):
     ap.add_argument("--max-queue-delay", type=float, default=None,
                     help="shed requests not admitted after this many seconds (default: 4 × the TTFT SLO)")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-gemm-tune", action="store_true", help="skip the start-up GEMM dispatch measurement (A/B)")
     ap.add_argument("--no-mixed-graphs", action="store_true", help="capture pure-decode steps only (A/B of the mixed-step graphs)")
     ap.add_argument("--no-custom-ar", action="store_true")
     ap.add_argument("--fcfs", action="store_true", help="plain FCFS admission (default: requests past their TTFT deadline yield)")
@@ -307,7 +308,8 @@ def main():
                                                custom_all_reduce=not args.no_custom_ar,
                                                ep_a2a_min_tokens=0 if args.emulate_tp > 1 else args.ep_a2a_min_tokens),
                        device=args.device, seed=args.seed, use_hip_graphs=on_gpu and not args.no_graphs,
-                       async_scheduling=False if args.sync_steps else None, mixed_step_graphs=not args.no_mixed_graphs)
+                       async_scheduling=False if args.sync_steps else None, mixed_step_graphs=not args.no_mixed_graphs,
+                       tune_gemms=not args.no_gemm_tune)
     t_load = time.perf_counter()
     eng = LLMEngine(cfg, ctx, dev)
     note(f"model built in {time.perf_counter() - t_load:.1f} s, {eng.runner.kv_cache_tokens} KV tokens; warming up")

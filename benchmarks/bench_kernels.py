@@ -292,6 +292,61 @@ def bench_gemm256(quick):
                speedup=round(ts[128] / ts[256], 3))
 
 
+def bench_midm(quick):
+    """the library GEMM (hipBLASLt) and the path `ops` dispatches against the roofline
+    max(weight bytes / 5.8 TB/s, FLOPs / 2.0 PFLOP/s) for every projection of Llama-3-8B, Llama-3-70B and the 70B TP = 8
+    shard at M = 64 … 2048 (where decode-heavy TP = 8 steps live), GPU time inside hipGraphs, weights rotated past the
+    infinity cache.  `off_roofline` > 1.25 marks the shapes a hand-written mid-M tile would have to beat."""
+    import torch.nn.functional as F
+    lib = ops.hip()
+    models = {
+        "8b": [("qkv", 6144, 4096, False), ("o", 4096, 4096, False), ("gate_up", 28672, 4096, True), ("down", 4096, 14336, False)],
+        "70b_tp8": [("qkv", 1280, 8192, False), ("o", 8192, 1024, False), ("gate_up", 7168, 8192, True), ("down", 8192, 3584, False)],
+        "70b": [("qkv", 10240, 8192, False), ("o", 8192, 8192, False), ("gate_up", 57344, 8192, True), ("down", 8192, 28672, False)],
+    }
+    ms_env = os.environ.get("DLI_BENCH_MIDM_MS")           # e.g. "2304,2816,3328": the step sizes of the saturated 8B loop
+    only_models = os.environ.get("DLI_BENCH_MIDM_MODELS")
+    for model, shapes in (list(models.items())[:1] if quick else models.items()):
+        if only_models and model not in only_models.split(","):
+            continue
+        for name, N, K, swiglu in shapes:
+            copies = max(2, -(-(600 << 20) // (N * K * 2)))
+            ws = [(torch.randn(N, K, device=DEV) * 0.02).bfloat16() for _ in range(copies)]
+            for M in ((256,) if quick else tuple(int(v) for v in ms_env.split(",")) if ms_env else (64, 128, 256, 512, 1024, 2048)):
+                x = torch.randn(M, K, device=DEV).bfloat16()
+                state = {"i": 0}
+
+                def call(fn):
+                    def run():
+                        state["i"] = (state["i"] + 1) % copies
+                        return fn(x, ws[state["i"]])
+                    return run
+                t_lib = timeit_graph(call(lambda a, w: F.linear(a, w)), 2 * copies)
+                if swiglu:
+                    t_lib_path = timeit_graph(call(lambda a, w: ops.silu_and_mul(F.linear(a, w))), 2 * copies)
+                    t_ops = timeit_graph(call(lambda a, w: ops.linear_swiglu(a, w)), 2 * copies)
+                else:
+                    t_lib_path = t_lib
+                    t_ops = timeit_graph(call(lambda a, w: ops.linear(a, w)), 2 * copies)
+                fl = 2.0 * M * N * K
+                roof = max(N * K * 2 / 5.8e12, fl / 2.0e15)
+                # the 256² tile with K cut into slices (fp32 partial slabs + reduce pass), whatever `ops` would pick
+                sk = {}
+                n_out = N // 2 if swiglu else N
+                if n_out % (128 if swiglu else 256) == 0 and N * K * 2 < 2 ** 32 and os.environ.get("DLI_BENCH_SPLITK", "1") != "0":
+                    for ksp in (1, 2, 4, 8, 16):
+                        if ksp <= K // 256:
+                            sk[ksp] = round(timeit_graph(call(lambda a, w: lib.dense_gemm256(a, w, swiglu, ksp)), 2 * copies) * 1e6, 1)
+                best_sk = min(sk, key=sk.get) if sk else None
+                report(f"midm({model}_{name})", t_ops, flops=fl, M=M, N=N, K=K, library_gemm_us=round(t_lib * 1e6, 1),
+                       tile256_splitk_us=sk, best_splitk=best_sk,
+                       best_splitk_vs_library_path=round(t_lib_path * 1e6 / sk[best_sk], 3) if sk else None,
+                       library_path_us=round(t_lib_path * 1e6, 1), roofline_us=round(roof * 1e6, 1),
+                       library_off_roofline=round(t_lib / roof, 2), dispatched_off_roofline=round(t_ops / roof, 2),
+                       dispatched_vs_library_path=round(t_lib_path / t_ops, 3))
+            del ws
+
+
 def bench_linear(quick):
     """Decode-sized linear layers: the weight-streaming kernel against the library GEMM (hipBLASLt via torch).
     Weights rotate through ≥ 1 GB of copies so that no call finds its matrix in the 256 MB infinity cache."""
@@ -360,6 +415,8 @@ def main():
         bench_gemm256(a.quick)
     if run("linear"):
         bench_linear(a.quick)
+    if only and run("midm"):                                  # on request only (minutes: 3 models × 4 projections × 6 sizes)
+        bench_midm(a.quick)
 
 
 if __name__ == "__main__":

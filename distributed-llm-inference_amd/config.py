@@ -184,6 +184,9 @@ class EngineConfig:
     # steps that hold prefill chunks replay captured graphs too (body keyed by the padded token count + LM-head/sampler
     # graph keyed by the padded number of sampled rows); off: only pure-decode steps are captured
     mixed_step_graphs: bool = True
+    # time library GEMM vs the own 256² tile (split-K variants) per projection shape and captured row count at start-up
+    # and dispatch on the result (ops/gemm_plan.py); off: library above 64 rows, except the gate/up heuristics
+    tune_gemms: bool = True
     weights_path: Optional[str] = None      # safetensors dir/file; None → random init
     tokenizer_path: Optional[str] = None    # HF tokenizer.json; None → byte-level tokenizer
 

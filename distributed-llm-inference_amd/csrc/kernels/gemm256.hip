@@ -30,6 +30,8 @@
 //     columns of one row: 8-byte row-contiguous stores, and the SwiGLU pair (gate column, up column) of a row
 //     lives in the same lane.
 //   * block → tile mapping: XCD x runs the x-th eighth of the tile order (8-column groups, row tile, column).
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -41,7 +43,11 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int TILE_BYTES = TM * TK * 2;        // one operand tile of one K-step: 32 KB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
 
-enum { EPI_SWIGLU = 0, EPI_SCATTER = 1, EPI_SCATTER_SPLITK = 2, EPI_PLAIN = 3 };
+enum { EPI_SWIGLU = 0, EPI_SCATTER = 1, EPI_SCATTER_SPLITK = 2, EPI_PLAIN = 3, EPI_PLAIN_SPLITK = 4, EPI_SWIGLU_SPLITK = 5 };
+// The two dense split-K epilogues (mid-M GEMMs: one or two row tiles cannot fill 256 CUs, so K is cut into slices) store
+// raw fp32 partial sums into slab `split` of a workspace [k_splits][M][ldc]; splitk_reduce_kernel adds the slabs in
+// fixed order and applies the real epilogue (bf16 store, or silu(gate)·up over the [gate | up] halves of a row).
+constexpr bool is_swiglu(int epi) { return epi == EPI_SWIGLU || epi == EPI_SWIGLU_SPLITK; }
 
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
 
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   const int col_block = col_virtual - split * n_col_blocks;
   const int e = GROUPED ? tile_expert[tile] : 0;
   const uint16_t* We = W + (int64_t)e * w_expert_stride;
-  const int n0 = col_block * (EPI == EPI_SWIGLU ? TN / 2 : TN);
+  const int n0 = col_block * (is_swiglu(EPI) ? TN / 2 : TN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int col = lane & 15, g = lane >> 4;
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
       b_dst[h][jj] = br0 * 128;
       const int ar = ar0 + (lane >> 3), br = br0 + (lane >> 3);
       int64_t arow;
-      if (GROUPED && EPI == EPI_SWIGLU) {
+      if (GROUPED && is_swiglu(EPI)) {
         const int sid = sorted_ids[tile * TM + ar];
         arow = sid >= 0 ? sid / top_k : 0;                   // padding rows read token 0 (discarded later)
       } else if (GROUPED) {
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
       }
       a_src[h][jj] = (uint32_t)((arow * a_stride + (((lane & 7) ^ (ar & 7)) * 8)) * 2);
       int wrow;
-      if (EPI == EPI_SWIGLU) {
+      if (is_swiglu(EPI)) {
         const int w_ = br >> 6, within = br & 63;             // wave column, position inside its 32 gate + 32 up rows
         wrow = (within < 32 ? 0 : N_half) + n0 + w_ * 32 + (within & 31);
       } else {
@@ -248,7 +254,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   for (int m = 0; m < 8; ++m) {
     const int prow = tile * TM + wr * 128 + m * 16 + col;
     const int sid = GROUPED ? sorted_ids[prow] : (prow < M ? prow : -1);
-    if (EPI == EPI_SWIGLU) {
+    if (EPI == EPI_PLAIN_SPLITK) {
+      if (sid >= 0) {
+        float* dst = reinterpret_cast<float*>(out_) + split * slab_elems + (int64_t)prow * out_stride + n0 + wc * 64 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + n * 16) = acc[m][n];
+      }
+    } else if (EPI == EPI_SWIGLU_SPLITK) {
+      if (sid >= 0) {                                            // raw partials: gate at column c, up at N_half + c of the slab row
+        float* dst = reinterpret_cast<float*>(out_) + split * slab_elems + (int64_t)prow * out_stride + n0 + wc * 32 + 4 * g;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          *reinterpret_cast<f32x4*>(dst + n * 16) = acc[m][n];
+          *reinterpret_cast<f32x4*>(dst + N_half + n * 16) = acc[m][n + 2];
+        }
+      }
+    } else if (EPI == EPI_SWIGLU) {
       // wave columns: n = 0,1 gate (32 columns), n = 2,3 the matching up columns
       if (GROUPED || sid >= 0) {
         uint16_t* dst = out + (int64_t)prow * out_stride + n0 + wc * 32 + 4 * g;
@@ -312,14 +333,62 @@ void launch_grouped_gemm256(int epilogue, const void* A, int64_t a_stride, const
 #undef G256_GO
 }
 
+// out[m][c] = Σ_s slab_s[m][c]  (SWIGLU: silu(Σ gate) · Σ up, gate at c and up at n_out + c of a slab row of 2·n_out)
+template <bool SWIGLU>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int n_slabs, int64_t slab_elems,
+                                                            int64_t ldc, int M, int n_out, uint16_t* __restrict__ out,
+                                                            int64_t out_stride) {
+  const int vec_per_row = n_out / 4;
+  const int64_t total = (int64_t)M * vec_per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / vec_per_row), c = (int)(i - (int64_t)m * vec_per_row) * 4;
+    const float* p = slabs + (int64_t)m * ldc + c;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_slabs; ++s) {
+      a += *reinterpret_cast<const f32x4*>(p + s * slab_elems);
+      if (SWIGLU) b += *reinterpret_cast<const f32x4*>(p + s * slab_elems + n_out);
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = SWIGLU ? a[r] * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * a[r])) * b[r] : a[r];
+      o[r] = (short)f2bf(v);
+    }
+    *reinterpret_cast<bf16x4*>(out + (int64_t)m * out_stride + c) = o;
+  }
+}
+
 // Dense y = x · Wᵀ (swiglu = false: W [N, K] → y [M, N]) or y = silu(x · W_gateᵀ) ⊙ (x · W_upᵀ)
 // (swiglu = true: W = [W_gate; W_up] of 2·N_out rows → y [M, N_out]).  K % 64 == 0, N_out % 256 (128 with swiglu) == 0.
+// k_splits > 1: K is cut into that many slices (each at least one K-step), partial sums go through `workspace`
+// (fp32, k_splits · M · (swiglu ? 2 : 1) · N_out elements) and a reduce pass — the mid-M path: with one or two row tiles
+// the column blocks alone leave most of the 256 CUs without a tile, and the GEMM is a weight stream that needs them all.
 void launch_dense_gemm256(bool swiglu, const void* x, int64_t x_stride, const void* W, void* out, int64_t out_stride, int M,
-                          int K, int N_out, hipStream_t stream) {
+                          int K, int N_out, int k_splits, float* workspace, hipStream_t stream) {
   using namespace g256;
   if (M == 0) return;
   const int n_tiles = (M + TM - 1) / TM;
   const int n_col_blocks = N_out / (swiglu ? TN / 2 : TN);
+  if (k_splits > 1) {
+    const int64_t ldc = (int64_t)N_out * (swiglu ? 2 : 1), slab = (int64_t)M * ldc;
+    dim3 grid((n_tiles * n_col_blocks * k_splits + 7) / 8 * 8);
+    if (swiglu)
+      hipLaunchKernelGGL((gemm256_kernel<EPI_SWIGLU_SPLITK, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
+                         (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, workspace, ldc, M, K, N_out,
+                         n_col_blocks, k_splits, slab);
+    else
+      hipLaunchKernelGGL((gemm256_kernel<EPI_PLAIN_SPLITK, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
+                         (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, workspace, ldc, M, K, N_out,
+                         n_col_blocks, k_splits, slab);
+    const int blocks = (int)std::min<int64_t>(((int64_t)M * (N_out / 4) + 255) / 256, 2048);
+    if (swiglu)
+      hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, workspace, k_splits, slab, ldc, M, N_out,
+                         (uint16_t*)out, out_stride);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, stream, workspace, k_splits, slab, ldc, M, N_out,
+                         (uint16_t*)out, out_stride);
+    return;
+  }
   dim3 grid((n_tiles * n_col_blocks + 7) / 8 * 8);
   if (swiglu)
     hipLaunchKernelGGL((gemm256_kernel<EPI_SWIGLU, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,

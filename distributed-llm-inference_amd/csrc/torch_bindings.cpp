@@ -246,7 +246,7 @@ void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
 }
 
 // y = x · Wᵀ on the 256×256×64 tile kernel (gemm256.hip); swiglu: W = [gate; up] rows, y = silu(x·gateᵀ) ⊙ (x·upᵀ)
-Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu) {
+Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_splits) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
@@ -254,9 +254,12 @@ Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu) {
   const int64_t n_out = swiglu ? N / 2 : N;
   TORCH_CHECK(K % 64 == 0 && n_out % (swiglu ? 128 : 256) == 0 && N % 2 == 0, "dense_gemm256: unsupported shape N=", N, " K=", K);
   TORCH_CHECK(M >= 1 && M * x.stride(0) * 2 < (int64_t(1) << 32) && N * K * 2 < (int64_t(1) << 32), "dense_gemm256: operand too large");
+  TORCH_CHECK(k_splits >= 1 && k_splits <= 32 && k_splits <= K / 64, "dense_gemm256: k_splits must be in [1, min(32, K / 64)]");
   Tensor out = at::empty({M, n_out}, x.options());
+  Tensor ws;                                                  // fp32 partial slabs of the split-K path
+  if (k_splits > 1) ws = at::empty({k_splits, M, N}, x.options().dtype(at::kFloat));
   dli::launch_dense_gemm256(swiglu, x.data_ptr(), x.stride(0), w.data_ptr(), out.data_ptr(), n_out, (int)M, (int)K, (int)n_out,
-                            cur_stream(x));
+                            (int)k_splits, k_splits > 1 ? ws.data_ptr<float>() : nullptr, cur_stream(x));
   return out;
 }
 
@@ -446,7 +449,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False) -> Tensor", &skinny_linear);
-  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False) -> Tensor", &dense_gemm256);
+  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1) -> Tensor", &dense_gemm256);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
         "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale, Tensor? kv_scales=None) -> ()",
         &rope_and_cache);

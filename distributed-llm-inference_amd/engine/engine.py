@@ -258,6 +258,7 @@ class LLMEngine:
                 with open(self.cfg.cache.calibration_file, encoding="utf-8", errors="replace") as fh:
                     ids = np.asarray(self.tokenizer.encode(fh.read()), dtype=np.int64) % self.cfg.model.vocab_size
             self.runner.calibrate_kv_scales(ids if ids is not None and len(ids) >= 16 else None)
+        self.runner.tune_gemms()                             # measured GEMM dispatch: the captured steps hold its choices
         self.runner.selftest_overlap()                       # decides what the captured steps will contain
         if capture_graphs:
             self.runner.capture_all()

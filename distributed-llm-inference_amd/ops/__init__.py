@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import reference as ref
+from .gemm_plan import PLAN as _PLAN
 from .kv_layout import allocate_kv_cache, bytes_per_block, kv_cache_shapes  # noqa: F401
 
 _SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C.so")
@@ -237,11 +238,23 @@ def _skinny_ok(x: torch.Tensor, weight: torch.Tensor, row_multiple: int) -> bool
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
 
+def _tile_operand_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous()
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
+            and x.shape[0] * x.stride(0) * 2 < 2 ** 32 and weight.numel() * 2 < 2 ** 32)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x @ weightᵀ + bias``.  Decode-sized GPU inputs take the weight-streaming MFMA kernel
-    (``csrc/kernels/skinny_gemm.hip``); everything else is a plain library GEMM (hipBLASLt through torch)."""
+    (``csrc/kernels/skinny_gemm.hip``); above that the start-up measurement (``ops/gemm_plan.py``) says, per layer shape
+    and row count, whether the library GEMM (hipBLASLt through torch) or the own 256² tile — with K cut into slices at
+    mid-M — runs; shapes it never measured go to the library."""
     if _skinny_ok(x, weight, 16):
         return hip().skinny_linear(x, weight, bias, False)
+    if bias is None and _PLAN.table and x.is_cuda and x.dim() == 2:
+        s = _PLAN.splits_for(x.shape[0], weight.shape[0], weight.shape[1], False)
+        if s and _tile_operand_ok(x, weight):
+            return hip().dense_gemm256(x, weight, False, s)
     return torch.nn.functional.linear(x, weight, bias)
 
 
@@ -266,6 +279,12 @@ def linear_swiglu(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     GEMM: the ``[T, 2·I]`` intermediate never exists), library GEMM + ``silu_and_mul`` in between."""
     if _skinny_ok(x, weight, 32):
         return hip().skinny_linear(x, weight, None, True)
+    if _PLAN.table and x.is_cuda and x.dim() == 2:          # measured at start-up for this shape and row count
+        s = _PLAN.splits_for(x.shape[0], weight.shape[0], weight.shape[1], True)
+        if s is not None:
+            if s and _tile_operand_ok(x, weight):
+                return hip().dense_gemm256(x, weight, True, s)
+            return silu_and_mul(torch.nn.functional.linear(x, weight))
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous()
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
             and gemm256_swiglu_ok(x.shape[0], weight.shape[0] // 2, weight.shape[1])

@@ -841,6 +841,44 @@ class ModelRunner:
         return res
 
     @torch.inference_mode()
+    def tune_gemms(self) -> dict:
+        """Fill the measured GEMM dispatch table (``ops/gemm_plan.py``) for this model's projections at exactly the row
+        counts the captured steps use (decode buckets, mixed token buckets; the LM head at the sampled-row buckets).
+        TP rank 0 measures, the group shares its table."""
+        from ..ops import gemm_plan
+        if not (self.on_gpu and gemm_plan.ENABLED and self.cfg.tune_gemms):
+            return {}
+        plan = gemm_plan.PLAN
+        blob = None
+        if self.ctx.is_driver:
+            from ..models.llama import Attention, SwiGLUMLP
+            groups: dict = {}
+
+            def add(name, w, swiglu):
+                groups.setdefault((name, tuple(w.shape), swiglu), []).append(w)
+            for mod in self.model.modules():
+                if isinstance(mod, Attention):
+                    add("qkv", mod.qkv.weight.data, False)
+                    add("o", mod.o.weight.data, False)
+                elif isinstance(mod, SwiGLUMLP):
+                    add("gate_up", mod.gate_up.weight.data, True)
+                    add("down", mod.down.weight.data, False)
+            B = self.cfg.sched.max_num_seqs
+            decode_rows = [b for b in self.cfg.graph_batch_sizes if b <= B]
+            rows = sorted(set(decode_rows) | set(self.mixed_buckets if self.cfg.mixed_step_graphs else ()))
+            plan.tune([(k[0], v, k[2]) for k, v in groups.items()], rows, self.device)
+            head = getattr(self.model, "lm_head", None)
+            if head is not None and getattr(head, "weight", None) is not None:
+                plan.tune([("lm_head", [head.weight.data], False)], decode_rows, self.device, budget_s=20.0)
+            blob = plan.export()
+        if self.ctx.distributed:
+            blob = self.ctx.broadcast_object(blob, src=0)
+            if not self.ctx.is_driver:
+                plan.load(blob)
+        self.selftest["gemm_plan"] = plan.summary() if self.ctx.is_driver else {"entries": sum(len(v) - 1 for v in plan.table.values())}
+        return self.selftest["gemm_plan"]
+
+    @torch.inference_mode()
     def selftest_overlap(self) -> dict:
         """GEMM / all-reduce pipeline of ``RowParallelLinear`` against GEMM → all-reduce, then the timing gate.  Runs
         BEFORE the graphs are captured: the captured steps hold whichever path this leaves switched on."""

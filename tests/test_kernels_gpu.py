@@ -392,6 +392,31 @@ def test_dense_gemm256_swiglu_epilogue(M, I, K):
     assert (got - want).abs().max() / want.abs().max() < 1.5e-2
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(128, 512, 1024, 4), (300, 4096, 14336, 16), (64, 256, 512, 2), (511, 1280, 8192, 8)])
+def test_dense_gemm256_split_k_matches_fp32_reference(M, N, K, ks):
+    """Mid-M path: K cut into slices, fp32 partial slabs, reduce pass — rows past M never stored,
+    uneven slices (K / 64 not divisible by the split count) covered."""
+    x = _bf(M, K, seed=71)
+    w = _bf(N, K, seed=72, scale=0.05)
+    got = ops.hip().dense_gemm256(x, w, False, ks).float()
+    want = x.float() @ w.float().t()
+    assert got.shape == (M, N) and torch.isfinite(got).all()
+    assert (got - want).abs().max() / want.abs().max() < 1e-2
+    one = ops.hip().dense_gemm256(x, w, False, 1).float()
+    assert (got - one).abs().max() / want.abs().max() < 1e-2
+
+
+@pytest.mark.parametrize("M,I,K,ks", [(128, 256, 1024, 4), (200, 3584, 8192, 8), (33, 128, 320, 5)])
+def test_dense_gemm256_split_k_swiglu(M, I, K, ks):
+    x = _bf(M, K, seed=73)
+    w = _bf(2 * I, K, seed=74, scale=0.05)
+    got = ops.hip().dense_gemm256(x, w, True, ks).float()
+    h = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(h[:, :I]) * h[:, I:]
+    assert got.shape == (M, I) and torch.isfinite(got).all()
+    assert (got - want).abs().max() / want.abs().max() < 1.5e-2
+
+
 def test_dense_gemm256_identity_check_with_asymmetric_weights():
     """A = I with an asymmetric W: catches a transposed or permuted C write that symmetric data would hide."""
     K = N = 256

@@ -69,6 +69,22 @@ def test_tp8_matches_tp1_on_gpu(model, ep):
     assert all(a[:2] == b[:2] for a, b in zip(one["greedy"], eight["greedy"])) and agree >= 0.8, (one, eight)
 
 
+@pytest.mark.parametrize("model,ep", [("tiny-llama-tp8", 1), ("tiny-mixtral-tp8", 8)])
+def test_tp8_logits_track_tp1(model, ep, tmp_path):
+    """a logit-level pin at the degree of configs 4 and 5 next to the token-agreement one — the first
+    served step's logits of 8 ranks (8-peer custom all-reduce / all-gather, one expert per rank) against one rank."""
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (21, 50)]
+    logits = {}
+    for tp, e in ((1, 1), (8, ep)):
+        f = str(tmp_path / f"logits_tp{tp}.pt")
+        out = run(model, tp, e, prompts, {"DLI_DUMP_LOGITS": f})
+        assert out["custom_ar"] == (tp > 1)
+        logits[tp] = torch.load(f, weights_only=True)
+    cos = torch.nn.functional.cosine_similarity(logits[1], logits[8], dim=0).item()
+    assert cos > 0.999, cos
+
+
 @pytest.mark.parametrize("model,ep", [("llama3-8b", 1), ("mixtral-8x7b", 2), ("mixtral-8x7b", 1)])
 def test_tp2_real_shapes_logits_track_tp1(model, ep, tmp_path):
     """Full-width layers (H 4096, 32/8 heads, FFN 14336, 8 experts, real vocabularies), 4 of them to keep it
