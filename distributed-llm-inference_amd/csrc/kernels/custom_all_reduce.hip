@@ -223,6 +223,181 @@ __global__ __launch_bounds__(kThreads) void broadcast_kernel(Peers p, int rank, 
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
 }
 
+// ==================================================================================================
+// Expert-parallel dispatch / combine over the same IPC buffers (K8 "EP dispatch/combine via all-to-all"): every rank
+// routes ITS slice of the step's tokens, the (token, expert) rows travel to the rank that owns the expert, the expert
+// outputs travel back.  No host in the loop: the per-destination counts live in device memory that the peers read.
+//
+//   ep_plan   (1 workgroup)   bucket my n = tokens·k pairs by destination rank → slot[i] (row in my send area, grouped
+//                             by destination) and send_off[0..world] in the EpMeta block at the tail of MY staging buffer
+//   ep_pack                   copy the pairs' activation rows, expert ids and gate weights into MY staging buffer at slot[i]
+//   ep_exchange (B blocks)    barrier → read every peer's send_off → pull "rows for me" from each peer's staging into a
+//                             local compact buffer (ordered by source rank), ids / weights alongside, -1 ids behind the
+//                             last valid row; publish recv_off[src] (where each source's rows start) → barrier
+//   … grouped GEMMs of the local experts on the received rows, output written into MY result buffer (IPC-visible) …
+//   ep_combine (B blocks)     barrier → every pair pulls its output row from the owner's result buffer → barrier
+//
+// All cross-rank data is produced by an EARLIER kernel of the producing rank and read after a mesh barrier inside the
+// consuming kernel — the publish / consume recipe of the all-reduce kernels (release before the flag, acquire + invalidate
+// after the wait), so one barrier per kernel suffices and no block pairing is needed.  Same grid on every rank.
+// ==================================================================================================
+struct EpMeta {
+  int send_off[kMaxRanks + 1];   // my staging rows [send_off[d], send_off[d+1]) are for rank d
+  int recv_off[kMaxRanks + 1];   // in my result buffer, the rows received from rank s start at recv_off[s]
+};
+constexpr int kEpMetaBytes = 512;
+
+__global__ __launch_bounds__(1024) void ep_plan_kernel(const int* __restrict__ ids, int n, int local_experts, int world,
+                                                       int* __restrict__ slot, EpMeta* __restrict__ meta) {
+  __shared__ int cnt[kMaxRanks], off[kMaxRanks + 1], fill[kMaxRanks];
+  if (threadIdx.x < kMaxRanks) { cnt[threadIdx.x] = 0; fill[threadIdx.x] = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&cnt[min(ids[i] / local_experts, world - 1)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    off[0] = 0;
+    for (int d = 0; d < world; ++d) off[d + 1] = off[d] + cnt[d];
+    for (int d = 0; d <= world; ++d) meta->send_off[d] = off[d];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int d = min(ids[i] / local_experts, world - 1);
+    slot[i] = off[d] + atomicAdd(&fill[d], 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void ep_pack_kernel(const uint16_t* __restrict__ x, int64_t x_stride, const int* __restrict__ ids,
+                                                      const float* __restrict__ wts, const int* __restrict__ slot, int n, int top_k,
+                                                      int H, uint16_t* __restrict__ rows, int* __restrict__ ids_st,
+                                                      float* __restrict__ wts_st) {
+  const int vpr = H / 8;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const int s = slot[i];
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(x + (int64_t)(i / top_k) * x_stride);
+    bf16x8* dst = reinterpret_cast<bf16x8*>(rows + (int64_t)s * H);
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) dst[v] = src[v];
+    if (threadIdx.x == 0) { ids_st[s] = ids[i]; wts_st[s] = wts[i]; }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void ep_exchange_kernel(Peers p, int rank, int world, int H, int64_t ids_off,
+                                                               int64_t wts_off, int64_t meta_off, uint16_t* __restrict__ recv_x,
+                                                               int* __restrict__ ids_local, float* __restrict__ w_local,
+                                                               int r_cap, int* __restrict__ recv_total) {
+  Signal* self = p.signal[rank];
+  const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  mesh_barrier<0>(p, rank, world, flag);
+  __shared__ int s_off[kMaxRanks], roff[kMaxRanks + 1];
+  if (threadIdx.x < world) {
+    const EpMeta* m = reinterpret_cast<const EpMeta*>(reinterpret_cast<const char*>(p.staging[threadIdx.x]) + meta_off);
+    s_off[threadIdx.x] = m->send_off[rank];
+    roff[threadIdx.x + 1] = m->send_off[rank + 1] - m->send_off[rank];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    roff[0] = 0;
+    for (int s = 0; s < world; ++s) roff[s + 1] = min(roff[s] + roff[s + 1], r_cap);
+  }
+  __syncthreads();
+  const int R = roff[world];
+  const int vpr = H / 8;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = tid; idx < (int64_t)R * vpr; idx += stride) {
+    const int r = (int)(idx / vpr), v = (int)(idx - (int64_t)r * vpr);
+    int s = 0;
+    while (r >= roff[s + 1]) ++s;
+    const int64_t srow = s_off[s] + (r - roff[s]);
+    reinterpret_cast<bf16x8*>(recv_x)[idx] = reinterpret_cast<const bf16x8*>(p.staging[s])[srow * vpr + v];
+  }
+  for (int64_t r = tid; r < r_cap; r += stride) {
+    if (r < R) {
+      int s = 0;
+      while (r >= roff[s + 1]) ++s;
+      const int64_t srow = s_off[s] + (r - roff[s]);
+      const char* base = reinterpret_cast<const char*>(p.staging[s]);
+      ids_local[r] = reinterpret_cast<const int*>(base + ids_off)[srow];
+      w_local[r] = reinterpret_cast<const float*>(base + wts_off)[srow];
+    } else {
+      ids_local[r] = -1;                                     // no expert: the alignment kernel skips the row
+      w_local[r] = 0.f;
+    }
+  }
+  if (blockIdx.x == 0) {
+    EpMeta* mine = reinterpret_cast<EpMeta*>(reinterpret_cast<char*>(p.staging[rank]) + meta_off);
+    if (threadIdx.x <= world) mine->recv_off[threadIdx.x] = roff[threadIdx.x];
+    if (threadIdx.x == 0) *recv_total = R;
+  }
+  mesh_barrier<2>(p, rank, world, flag);
+  if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+}
+
+__global__ __launch_bounds__(kThreads) void ep_combine_kernel(Peers p, int rank, int world, int H, int64_t meta_off,
+                                                              const int* __restrict__ ids, const int* __restrict__ slot, int n,
+                                                              int local_experts, uint16_t* __restrict__ y_back) {
+  Signal* self = p.signal[rank];
+  const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  mesh_barrier<0>(p, rank, world, flag);
+  __shared__ int send_off[kMaxRanks + 1], peer_roff[kMaxRanks];
+  if (threadIdx.x <= world)
+    send_off[threadIdx.x] = reinterpret_cast<const EpMeta*>(reinterpret_cast<const char*>(p.staging[rank]) + meta_off)->send_off[threadIdx.x];
+  if (threadIdx.x < world)
+    peer_roff[threadIdx.x] = reinterpret_cast<const EpMeta*>(reinterpret_cast<const char*>(p.staging[threadIdx.x]) + meta_off)->recv_off[rank];
+  __syncthreads();
+  const int vpr = H / 8;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t idx = tid; idx < (int64_t)n * vpr; idx += stride) {
+    const int i = (int)(idx / vpr), v = (int)(idx - (int64_t)i * vpr);
+    const int d = min(ids[i] / local_experts, world - 1);
+    const int64_t row = peer_roff[d] + (slot[i] - send_off[d]);
+    reinterpret_cast<bf16x8*>(y_back)[idx] = reinterpret_cast<const bf16x8*>(p.result[d])[row * vpr + v];
+  }
+  mesh_barrier<2>(p, rank, world, flag);
+  if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+}
+
+// Byte layout of the send area inside a staging buffer for at most n_cap pairs of H-wide rows; < 0 if it does not fit.
+int64_t ep_layout(void* st, int64_t n_cap, int H, int64_t* ids_off, int64_t* wts_off, int64_t* meta_off) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  const int64_t rows = (n_cap * H * 2 + 255) / 256 * 256;
+  *ids_off = rows;
+  *wts_off = rows + (n_cap * 4 + 255) / 256 * 256;
+  *meta_off = (int64_t)s->max_bytes - kEpMetaBytes;
+  return (*wts_off + n_cap * 4 <= *meta_off) ? 0 : -1;
+}
+void* ep_result_ptr(void* st) { ARState* s = reinterpret_cast<ARState*>(st); return s->peers.result[s->rank]; }
+int64_t ep_max_bytes(void* st) { return (int64_t) reinterpret_cast<ARState*>(st)->max_bytes; }
+
+int launch_ep_dispatch(void* st, const void* x, int64_t x_stride, const int* ids, const float* wts, int n, int n_cap, int top_k,
+                       int H, int local_experts, int* slot, void* recv_x, int* ids_local, float* w_local, int r_cap,
+                       int* recv_total, int blocks, hipStream_t stream) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  int64_t ids_off, wts_off, meta_off;
+  if (H % 8 || n > n_cap || ep_layout(st, n_cap, H, &ids_off, &wts_off, &meta_off) < 0) return -1;
+  if ((int64_t)r_cap * H * 2 > (int64_t)s->max_bytes) return -1;
+  char* mine = reinterpret_cast<char*>(s->peers.staging[s->rank]);
+  hipLaunchKernelGGL(ep_plan_kernel, dim3(1), dim3(1024), 0, stream, ids, n, local_experts, s->world, slot,
+                     reinterpret_cast<EpMeta*>(mine + meta_off));
+  if (n > 0)
+    hipLaunchKernelGGL(ep_pack_kernel, dim3(std::min(n, 2048)), dim3(256), 0, stream, (const uint16_t*)x, x_stride, ids, wts, slot, n,
+                       top_k, H, reinterpret_cast<uint16_t*>(mine), reinterpret_cast<int*>(mine + ids_off),
+                       reinterpret_cast<float*>(mine + wts_off));
+  blocks = std::max(1, std::min(blocks, kMaxBlocks));
+  hipLaunchKernelGGL(ep_exchange_kernel, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, s->world, H, ids_off, wts_off,
+                     meta_off, (uint16_t*)recv_x, ids_local, w_local, r_cap, recv_total);
+  return 0;
+}
+
+int launch_ep_combine(void* st, const int* ids, const int* slot, int n, int n_cap, int H, int local_experts, void* y_back, int blocks,
+                      hipStream_t stream) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  int64_t ids_off, wts_off, meta_off;
+  if (ep_layout(st, n_cap, H, &ids_off, &wts_off, &meta_off) < 0) return -1;
+  blocks = std::max(1, std::min(blocks, kMaxBlocks));
+  hipLaunchKernelGGL(ep_combine_kernel, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, s->world, H, meta_off, ids, slot, n,
+                     local_experts, (uint16_t*)y_back);
+  return 0;
+}
+
 // ---- host API (opaque handle; pointers are exchanged by the python layer through hipIpc handles) ----
 void* ar_alloc(size_t bytes, bool uncached) {
   void* p = nullptr;

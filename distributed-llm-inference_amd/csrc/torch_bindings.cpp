@@ -275,6 +275,42 @@ const int64_t g_moe_splitk_min_blocks256 = std::getenv("DLI_MOE_SPLITK_MIN_BLOCK
 const int64_t g_moe_skinny_max_t = std::getenv("DLI_NO_SKINNY_MOE") ? 0
                                    : std::getenv("DLI_SKINNY_MOE_MAX_T") ? std::atoll(std::getenv("DLI_SKINNY_MOE_MAX_T")) : 32;
 
+// align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum over the slots of a token, for (token,
+// slot) pairs whose expert ids / gate weights are already on the device (``ids`` < 0 or outside the local range: skipped).
+// ``out``: [T, H] bf16 (any device memory: the expert-parallel path hands in its IPC-visible result buffer).
+void moe_experts_forward(const Tensor& x, const Tensor& ids, const Tensor& wts, const Tensor& w13, const Tensor& w2, int64_t top_k,
+                         int64_t expert_offset, bool big, void* out, hipStream_t stream) {
+  const int64_t T = x.size(0), H = x.size(1), El = w13.size(0), I = w13.size(1) / 2;
+  const int64_t n = T * top_k;
+  auto i32 = x.options().dtype(at::kInt);
+  const int64_t TR = big ? 256 : 128;
+  const int64_t capacity = (n + TR - 1) / TR * TR + El * TR;
+  const int64_t max_tiles = capacity / TR;
+  Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
+  Tensor act = at::empty({capacity, I}, x.options());
+  // Down projection: with few row tiles (decode-sized batches) a (row tile × 128 columns) grid cannot fill 256 CUs and
+  // every block would stream a 3.7 MB weight panel through a 16 KB-deep pipeline, so K is cut into slices whose fp32
+  // partial slabs are summed (in fixed order) by moe_sum.  The slice count depends on T only: static under hipGraph.
+  const int64_t col_blocks2 = H / TR, nk2 = I / 64;
+  int64_t k_splits = 1;
+  // (512-thread 256² tiles run one per CU: two full rounds of the chip are enough; the 128² tiles run 2–3 per CU)
+  const int64_t want_blocks = big ? g_moe_splitk_min_blocks256 : 1024;
+  if (max_tiles * col_blocks2 < want_blocks)
+    k_splits = std::min<int64_t>({(want_blocks + max_tiles * col_blocks2 - 1) / (max_tiles * col_blocks2), 16, nk2});
+  const bool split = k_splits > 1;
+  Tensor y = split ? at::empty({k_splits, n, H}, x.options().dtype(at::kFloat)) : at::empty({n, H}, x.options());
+  dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
+                        tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, (int)TR, stream);
+  auto gg = big ? dli::launch_grouped_gemm256 : dli::launch_grouped_gemm;
+  gg(0, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(), meta.data_ptr<int>(),
+     wts.data_ptr<float>(), (int)top_k, act.data_ptr(), I, (int)H, (int)I, (int)max_tiles, 1, 0, stream);
+  gg(split ? 2 : 1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
+     meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H, (int)I, (int)H, (int)max_tiles, (int)k_splits,
+     n * H, stream);
+  dli::launch_moe_sum(y.data_ptr(), split, (int)k_splits, n * H, ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k,
+                      (int)T, (int)H, out, stream);
+}
+
 // ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
                  int64_t expert_offset, int64_t tile_rows) {
@@ -322,29 +358,8 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
                         (int)H, out.data_ptr(), stream);
     return out;
   }
-  Tensor act = at::empty({capacity, I}, x.options());
-  // Down projection: with few row tiles (decode-sized batches) a (row tile × 128 columns) grid cannot fill 256 CUs and
-  // every block would stream a 3.7 MB weight panel through a 16 KB-deep pipeline, so K is cut into slices whose fp32
-  // partial slabs are summed (in fixed order) by moe_sum.  The slice count depends on T only: static under hipGraph.
-  const int64_t col_blocks2 = H / TR, nk2 = I / 64;
-  int64_t k_splits = 1;
-  // (512-thread 256² tiles run one per CU: two full rounds of the chip are enough; the 128² tiles run 2–3 per CU)
-  const int64_t want_blocks = big ? g_moe_splitk_min_blocks256 : 1024;
-  if (max_tiles * col_blocks2 < want_blocks)
-    k_splits = std::min<int64_t>({(want_blocks + max_tiles * col_blocks2 - 1) / (max_tiles * col_blocks2), 16, nk2});
-  const bool split = k_splits > 1;
-  Tensor y = split ? at::empty({k_splits, n, H}, x.options().dtype(at::kFloat)) : at::empty({n, H}, x.options());
   dli::launch_moe_route(router_logits.data_ptr(), (int)T, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
-  dli::launch_moe_align(ids.data_ptr<int>(), (int)n, (int)expert_offset, (int)El, sorted.data_ptr<int>(),
-                        tile_expert.data_ptr<int>(), meta.data_ptr<int>(), (int)capacity, (int)TR, stream);
-  auto gg = big ? dli::launch_grouped_gemm256 : dli::launch_grouped_gemm;
-  gg(0, x.data_ptr(), H, w13.data_ptr(), 2 * I * H, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(), meta.data_ptr<int>(),
-     wts.data_ptr<float>(), (int)top_k, act.data_ptr(), I, (int)H, (int)I, (int)max_tiles, 1, 0, stream);
-  gg(split ? 2 : 1, act.data_ptr(), I, w2.data_ptr(), H * I, sorted.data_ptr<int>(), tile_expert.data_ptr<int>(),
-     meta.data_ptr<int>(), wts.data_ptr<float>(), (int)top_k, y.data_ptr(), H, (int)I, (int)H, (int)max_tiles, (int)k_splits,
-     n * H, stream);
-  dli::launch_moe_sum(y.data_ptr(), split, (int)k_splits, n * H, ids.data_ptr<int>(), (int)expert_offset, (int)El, (int)top_k,
-                      (int)T, (int)H, out.data_ptr(), stream);
+  moe_experts_forward(x, ids, wts, w13, w2, top_k, expert_offset, big, out.data_ptr(), stream);
   return out;
 }
 
@@ -385,6 +400,57 @@ void ar_all_reduce(int64_t st, const Tensor& inp, Tensor out, int64_t algo, int6
   const int rc = dli::launch_all_reduce(reinterpret_cast<void*>(st), inp.data_ptr(), out.data_ptr(), inp.numel() * 2, (int)algo,
                                         (int)blocks, cur_stream(inp));
   TORCH_CHECK(rc == 0, "custom all-reduce: message of ", inp.numel() * 2, " bytes not supported");
+}
+
+// ---- expert parallelism without the host: route my token slice, dispatch the (token, expert) rows to the
+// ranks that own the experts over the IPC buffers, run the local experts on what arrived, pull the outputs back, sum the
+// k slots of each token.  Every rank of the group calls this at the same point of its stream with the same n_cap.
+//   x_l [n_l, H] (n_l may be 0), router_logits_l [n_l, E]; n_cap: largest n_l · top_k over the ranks of this call.
+// Returns [n_l, H].
+Tensor ep_moe(int64_t st, const Tensor& x_l, const Tensor& router_logits_l, const Tensor& w13, const Tensor& w2, int64_t top_k,
+              int64_t n_cap, int64_t world, int64_t rank) {
+  TORCH_CHECK(x_l.is_cuda() && x_l.scalar_type() == at::kBFloat16 && x_l.dim() == 2 && x_l.is_contiguous());
+  TORCH_CHECK(router_logits_l.is_cuda() && router_logits_l.scalar_type() == at::kBFloat16 && router_logits_l.dim() == 2 &&
+              router_logits_l.is_contiguous() && router_logits_l.size(0) == x_l.size(0));
+  TORCH_CHECK(w13.is_cuda() && w2.is_cuda() && w13.is_contiguous() && w2.is_contiguous() && w13.scalar_type() == at::kBFloat16 &&
+              w2.scalar_type() == at::kBFloat16 && w13.dim() == 3 && w2.dim() == 3);
+  const int64_t n_l = x_l.size(0), H = x_l.size(1), E = router_logits_l.size(1), El = w13.size(0), I = w13.size(1) / 2;
+  TORCH_CHECK(El * world == E && E <= 64 && top_k >= 1 && top_k <= E && H % 128 == 0 && I % 64 == 0, "unsupported EP MoE shape");
+  TORCH_CHECK(w13.size(2) == H && w2.size(0) == El && w2.size(1) == H && w2.size(2) == I);
+  const int64_t n = n_l * top_k, r_cap = world * n_cap;
+  TORCH_CHECK(n <= n_cap, "ep_moe: n_cap smaller than this rank's pair count");
+  void* state = reinterpret_cast<void*>(st);
+  int64_t o1, o2, o3;
+  TORCH_CHECK(dli::ep_layout(state, n_cap, (int)H, &o1, &o2, &o3) == 0 && r_cap * H * 2 <= dli::ep_max_bytes(state),
+              "ep_moe: ", n_cap, " pairs of ", H, "-wide rows per rank do not fit the IPC buffers (process fewer tokens per call)");
+  auto stream = cur_stream(w13);
+  auto i32 = w13.options().dtype(at::kInt);
+  auto f32 = w13.options().dtype(at::kFloat);
+  Tensor ids = at::empty({std::max<int64_t>(n, 1)}, i32), wts = at::empty({std::max<int64_t>(n, 1)}, f32);
+  Tensor slot = at::empty({std::max<int64_t>(n, 1)}, i32), recv_total = at::empty({1}, i32);
+  Tensor recv_x = at::empty({r_cap, H}, w13.options()), ids_local = at::empty({r_cap}, i32), w_local = at::empty({r_cap}, f32);
+  if (n_l > 0)
+    dli::launch_moe_route(router_logits_l.data_ptr(), (int)n_l, (int)E, (int)top_k, ids.data_ptr<int>(), wts.data_ptr<float>(), stream);
+  const int blocks = 64;
+  int rc = dli::launch_ep_dispatch(state, x_l.data_ptr(), H, ids.data_ptr<int>(), wts.data_ptr<float>(), (int)n, (int)n_cap,
+                                   (int)top_k, (int)H, (int)El, slot.data_ptr<int>(), recv_x.data_ptr(), ids_local.data_ptr<int>(),
+                                   w_local.data_ptr<float>(), (int)r_cap, recv_total.data_ptr<int>(), blocks, stream);
+  TORCH_CHECK(rc == 0, "ep_moe: dispatch launch rejected");
+  // local experts on the received rows: one "slot" per row, gate weight applied here, output straight into the IPC result buffer.
+  // Row tile: the expected rows per local expert under uniform routing (what arrives is ≈ r_cap / world of the capacity)
+  bool big = (n_cap * world / std::max<int64_t>(world, 1)) / std::max<int64_t>(El, 1) >= g_moe_tile256_min_rows;
+  if (g_moe_tile_force) big = g_moe_tile_force == 256;
+  big = big && I % 128 == 0 && H % 256 == 0 && r_cap * std::max(H, I) * 2 < (int64_t(1) << 32) && 2 * I * H * 2 < (int64_t(1) << 32);
+  moe_experts_forward(recv_x, ids_local, w_local, w13, w2, 1, rank * El, big, dli::ep_result_ptr(state), stream);
+  Tensor y_back = at::empty({std::max<int64_t>(n, 1), H}, w13.options());
+  rc = dli::launch_ep_combine(state, ids.data_ptr<int>(), slot.data_ptr<int>(), (int)n, (int)n_cap, (int)H, (int)El, y_back.data_ptr(),
+                              blocks, stream);
+  TORCH_CHECK(rc == 0, "ep_moe: combine launch rejected");
+  Tensor out = at::empty({n_l, H}, w13.options());
+  if (n_l > 0)      // every slot counts (weights were applied by the owners): "all experts local" for the sum
+    dli::launch_moe_sum(y_back.data_ptr(), false, 1, n * H, ids.data_ptr<int>(), 0, (int)E, (int)top_k, (int)n_l, (int)H,
+                        out.data_ptr(), stream);
+  return out;
 }
 
 // launch-shape table chosen by the start-up sweep (identical on every rank of the group)
@@ -445,6 +511,8 @@ TORCH_LIBRARY(dli, m) {
   m.def("ar_ipc_close(int ptr) -> ()", &ar_ipc_close);
   m.def("ar_max_blocks() -> int", &ar_max_blocks);
   m.def("ar_all_gather(int state, Tensor inp, Tensor(a!) out) -> ()", &ar_all_gather);
+  m.def("ep_moe(int state, Tensor x_l, Tensor router_logits_l, Tensor w13, Tensor w2, int top_k, int n_cap, int world, int rank) -> Tensor",
+        &ep_moe);
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);

@@ -12,10 +12,13 @@ Expert parallelism (``ctx.ep_size == tp``): each rank owns ``E/tp`` whole expert
   TP group after the attention all-reduce, so every rank evaluates its own experts on the tokens routed
   to them and one all-reduce of ``[T, H]`` sums the partial outputs;
 * *all-to-all* (steps of ``ctx.ep_a2a_min_tokens`` tokens or more): each rank routes only its ``T/ep``
-  slice of the tokens, sends every (token, expert) row to the rank that owns the expert, runs the grouped
-  GEMM on what it received, returns the expert outputs and combines them; an all-gather of the ``T/ep``
-  result rows replicates the block output.  Per rank that moves ``≈ 2·top_k/ep + 1`` messages of ``T·H/ep``
-  rows' worth instead of the ``≈ 2·(ep-1)/ep · T·H`` of the all-reduce — 3.5× less over xGMI at ep = 8, top-2.
+  slice of the tokens (routing kernel), every (token, expert) row travels to the rank that owns the expert,
+  the grouped GEMM runs on what arrived, the expert outputs travel back and are combined; an all-gather of
+  the ``T/ep`` result rows replicates the block output.  Per rank that moves ``≈ 2·top_k/ep + 1`` messages of
+  ``T·H/ep`` rows' worth instead of the ``≈ 2·(ep-1)/ep · T·H`` of the all-reduce — 3.5× less over xGMI at
+  ep = 8, top-2.  The exchange runs on the IPC-mapped peer buffers of the custom collectives
+  (``csrc/kernels/custom_all_reduce.hip``: ``ep_plan / ep_pack / ep_exchange / ep_combine``) with the
+  per-destination counts kept in device memory: no host synchronisation, capturable in the step's hipGraph.
 """
 from __future__ import annotations
 
@@ -150,8 +153,7 @@ class MoEBlock(nn.Module):
 
     def forward(self, h):
         ctx = self.ctx
-        if (ctx.ep_size > 1 and 0 < ctx.ep_a2a_min_tokens <= h.shape[0]
-                and not (h.is_cuda and torch.cuda.is_current_stream_capturing())):
+        if ctx.ep_size > 1 and 0 < ctx.ep_a2a_min_tokens <= h.shape[0] and self._a2a_available(h):
             return self._forward_all_to_all(h)
         logits = self.router(h)
         if _EP_DEBUG and self.ctx.tp_size > 1 and not torch.cuda.is_current_stream_capturing():
@@ -159,24 +161,58 @@ class MoEBlock(nn.Module):
         out = ops.fused_moe(h, logits, self.w13.data, self.w2.data, self.top_k, self.expert_offset)
         return self.ctx.all_reduce(out)
 
+    def _a2a_available(self, h) -> bool:
+        """GPU: the dispatch runs on the custom IPC kernels (device-side counts, capturable) — without them the block
+        stays on the replicated path, which needs no host either.  CPU (tests): the torch reference of the same algorithm."""
+        if not h.is_cuda:
+            return self.ctx.distributed
+        ar = self.ctx.custom_ar
+        return (ar is not None and ar.enabled and h.dtype == torch.bfloat16 and h.shape[1] % 128 == 0
+                and ar.ep_tokens_per_call(h.shape[1], self.top_k) >= self.ctx.tp_size * 8)
+
     def _forward_all_to_all(self, h):
-        """Token-sliced routing + all-to-all dispatch/combine (see the module docstring).  The split sizes of the
-        exchange are data dependent, so the per-destination counts cross the host once per layer (one small D2H +
-        one gloo exchange): this path serves the large eager prefill steps, never a captured decode step."""
+        """Token-sliced routing + dispatch / combine (see the module docstring): each rank routes its ``T / ep`` rows with
+        the routing kernel, the IPC dispatch kernels move every (token, expert) row to the expert's owner and the outputs
+        back — the per-destination counts never leave the device (no ``.cpu()``, no gloo, no one-hot
+        detour in here) — and an all-gather of the result rows replicates the block output.  A step larger than the IPC
+        buffers' worst case goes through in several calls."""
+        if not h.is_cuda:
+            return self._forward_all_to_all_reference(h)
+        ctx, ep, k = self.ctx, self.ctx.tp_size, self.top_k
+        ar = ctx.custom_ar
+        T, H = h.shape
+        step = ar.ep_tokens_per_call(H, k)
+        outs = []
+        for t0 in range(0, T, step):
+            hp = h[t0:t0 + step]
+            Tp = hp.shape[0]
+            per = (Tp + ep - 1) // ep
+            lo = min(ctx.tp_rank * per, Tp)
+            hl = hp[lo:min(lo + per, Tp)]
+            out_l = ar.ep_moe(hl, self.router(hl), self.w13.data, self.w2.data, k, per * k)
+            ctx.comm["a2a_calls"] += 2
+            ctx.comm["a2a_bytes"] += 2 * hl.shape[0] * k * H * hl.element_size()
+            if out_l.shape[0] < per:                                         # the last rank's slice may be short
+                out_l = torch.cat([out_l, out_l.new_zeros(per - out_l.shape[0], H)])
+            outs.append(ctx.all_gather_rows(out_l)[:Tp])
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+    def _forward_all_to_all_reference(self, h):
+        """CPU reference of the dispatch (gloo; the multi-process CPU tests): same slicing, same owner computation, the
+        row exchange through ``dist.all_to_all_single`` with host-side split sizes."""
         import torch.distributed as dist
         ctx, ep, k = self.ctx, self.ctx.tp_size, self.top_k
         T, H = h.shape
         per = (T + ep - 1) // ep
         lo = min(ctx.tp_rank * per, T)
         hl = h[lo:min(lo + per, T)]
-        n_l = hl.shape[0]
         probs = torch.softmax(self.router(hl).float(), dim=-1)
         topv, topi = probs.topk(k, dim=-1)                                   # [n_l, k]
         topv = topv / topv.sum(-1, keepdim=True)
         flat_e = topi.reshape(-1)
         dest = torch.div(flat_e, self.local_experts, rounding_mode="floor")  # owner rank of every (token, k) row
         order = torch.sort(dest, stable=True).indices
-        send_counts = torch.bincount(dest, minlength=ep).cpu()
+        send_counts = torch.bincount(dest, minlength=ep)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts, group=ctx.cpu_group if ctx.cpu_group is not None else ctx.group)
         send_n, recv_n = send_counts.tolist(), recv_counts.tolist()
@@ -185,15 +221,13 @@ class MoEBlock(nn.Module):
         e_recv = ctx.all_to_all(flat_e.index_select(0, order).to(torch.int32), recv_n, send_n)
         R = x_recv.shape[0]
         if R:
-            # the grouped GEMM takes its expert assignment from router logits: a one-hot row with top-1 selects the
-            # expert that the source rank chose, with weight 1 (the gate weights are applied at the source)
-            onehot = torch.zeros(R, self.num_experts, dtype=h.dtype, device=h.device)
-            onehot.scatter_(1, e_recv.long().unsqueeze(1), 8.0)
+            onehot = torch.zeros(R, self.num_experts, dtype=h.dtype)
+            onehot.scatter_(1, e_recv.long().unsqueeze(1), 8.0)              # top-1 of a one-hot row = the chosen expert, weight 1
             y = ops.fused_moe(x_recv, onehot, self.w13.data, self.w2.data, 1, self.expert_offset)
         else:
             y = x_recv
         y_back = ctx.all_to_all(y, send_n, recv_n)                            # same order as the rows I sent
-        out_l = torch.zeros(per, H, dtype=torch.float32, device=h.device)
+        out_l = torch.zeros(per, H, dtype=torch.float32)
         out_l.index_add_(0, tok, y_back.float() * topv.reshape(-1).index_select(0, order).unsqueeze(1))
         return ctx.all_gather_rows(out_l.to(h.dtype))[:T]
 

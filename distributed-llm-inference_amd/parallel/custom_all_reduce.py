@@ -127,6 +127,20 @@ class CustomAllReduce:
         self.lib.ar_all_gather(self.state, x, out)
         return out
 
+    # ------------------------------------------------------------------ expert parallelism
+    def ep_tokens_per_call(self, hidden: int, top_k: int) -> int:
+        """Most tokens of a step one ``ep_moe`` call can take: in the worst routing every (token, expert) row lands on ONE
+        rank, whose result buffer (``max_bytes``) must hold them all."""
+        t = self.max_bytes // (top_k * hidden * 2)
+        return max(t // (self.world * 8) * (self.world * 8), 0)
+
+    def ep_moe(self, x_l: torch.Tensor, logits_l: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int,
+               n_cap: int) -> torch.Tensor:
+        """Expert-parallel MoE block for this rank's token slice ``x_l`` (see ``csrc/kernels/custom_all_reduce.hip``:
+        device-side routing, dispatch, local experts, combine — no host synchronisation, hipGraph-capturable).
+        ``n_cap``: the largest (tokens · top_k) any rank passes in this call."""
+        return self.lib.ep_moe(self.state, x_l.contiguous(), logits_l.contiguous(), w13, w2, top_k, n_cap, self.world, self.rank)
+
     def can_broadcast(self, buf: torch.Tensor) -> bool:
         nbytes = buf.numel() * buf.element_size()
         return (self.enabled and buf.is_cuda and buf.is_contiguous() and 0 < nbytes <= self.max_bytes

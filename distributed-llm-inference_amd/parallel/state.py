@@ -111,12 +111,7 @@ class ParallelContext:
         self.comm["a2a_calls"] += 1
         self.comm["a2a_bytes"] += x.numel() * x.element_size()
         if dist.get_backend(self.group) == "gloo" and x.is_cuda:
-            # gloo has no CUDA all_to_all: stage through the host (single-GPU rehearsal mode only)
-            o = torch.empty(out.shape, dtype=x.dtype)
-            dist.all_to_all_single(o, x.cpu().contiguous(), [int(n) for n in out_rows], [int(n) for n in in_rows],
-                                   group=self.group)
-            out.copy_(o)
-            return out
+            raise RuntimeError("device tensors are exchanged by the IPC dispatch kernels (CustomAllReduce.ep_moe), not through gloo")
         dist.all_to_all_single(out, x.contiguous(), [int(n) for n in out_rows], [int(n) for n in in_rows], group=self.group)
         return out
 

@@ -69,6 +69,28 @@ def test_tp8_matches_tp1_on_gpu(model, ep):
     assert all(a[:2] == b[:2] for a, b in zip(one["greedy"], eight["greedy"])) and agree >= 0.8, (one, eight)
 
 
+@pytest.mark.parametrize("model,tp", [("tiny-mixtral-tp", 2), ("tiny-mixtral-tp8", 8)])
+def test_ep_device_dispatch_matches_replicated_and_single_rank(model, tp, tmp_path):
+    """expert parallelism with the rows dispatched by the IPC kernels (routing kernel, device-side
+    per-destination counts, pull over the mapped buffers, combine) — no host sync, so the ≥ 64-token steps run it inside
+    the captured mixed graphs — against the replicated path (same ranks, all-reduce of partial sums) and one rank:
+    first-step logits and greedy tokens."""
+    rng = np.random.default_rng(6)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (300, 90, 7, 150)]
+    logits, outs = {}, {}
+    for name, t, e, env in (("one", 1, 1, {}), ("replicated", tp, tp, {"DLI_TEST_EP_A2A": "0"}), ("a2a", tp, tp, {"DLI_TEST_EP_A2A": "64"})):
+        f = str(tmp_path / f"logits_{name}.pt")
+        outs[name] = run(model, t, e, prompts, dict(env, DLI_DUMP_LOGITS=f))
+        logits[name] = torch.load(f, weights_only=True)
+    assert outs["a2a"]["a2a_calls"] > 0 and outs["replicated"]["a2a_calls"] == 0
+    assert outs["a2a"]["mixed_graph_steps"] > 0              # the dispatch was captured
+    for other in ("replicated", "one"):
+        cos = torch.nn.functional.cosine_similarity(logits["a2a"], logits[other], dim=0).item()
+        assert cos > 0.999, (other, cos)
+        agree = np.mean([np.mean(np.array(a) == np.array(b)) for a, b in zip(outs["a2a"]["greedy"], outs[other]["greedy"])])
+        assert agree >= 0.8, (other, agree, outs["a2a"]["greedy"], outs[other]["greedy"])
+
+
 @pytest.mark.parametrize("model,ep", [("tiny-llama-tp8", 1), ("tiny-mixtral-tp8", 8)])
 def test_tp8_logits_track_tp1(model, ep, tmp_path):
     """a logit-level pin at the degree of configs 4 and 5 next to the token-agreement one — the first
@@ -85,8 +107,8 @@ def test_tp8_logits_track_tp1(model, ep, tmp_path):
     assert cos > 0.999, cos
 
 
-@pytest.mark.parametrize("model,ep", [("llama3-8b", 1), ("mixtral-8x7b", 2), ("mixtral-8x7b", 1)])
-def test_tp2_real_shapes_logits_track_tp1(model, ep, tmp_path):
+@pytest.mark.parametrize("model,ep,a2a", [("llama3-8b", 1, 0), ("mixtral-8x7b", 2, 0), ("mixtral-8x7b", 1, 0), ("mixtral-8x7b", 2, 32)])
+def test_tp2_real_shapes_logits_track_tp1(model, ep, a2a, tmp_path):
     """Full-width layers (H 4096, 32/8 heads, FFN 14336, 8 experts, real vocabularies), 4 of them to keep it
     short: the first sampled row's logits of TP=2 must match TP=1 up to bf16 reduction noise."""
     rng = np.random.default_rng(1)
@@ -94,8 +116,9 @@ def test_tp2_real_shapes_logits_track_tp1(model, ep, tmp_path):
     logits = {}
     for tp, e in ((1, 1), (2, ep)):
         f = str(tmp_path / f"logits_tp{tp}.pt")
-        out = run(model, tp, e, prompts, {"DLI_TEST_LAYERS": "4", "DLI_DUMP_LOGITS": f})
+        out = run(model, tp, e, prompts, {"DLI_TEST_LAYERS": "4", "DLI_DUMP_LOGITS": f, "DLI_TEST_EP_A2A": str(a2a)})
         assert out["graph_steps"] > 0 and out["custom_ar"] == (tp > 1)
+        assert (out["a2a_calls"] > 0) == (tp > 1 and a2a > 0)     # a2a: the 51-token first step goes through the IPC dispatch
         logits[tp] = torch.load(f, weights_only=True)
     cos = torch.nn.functional.cosine_similarity(logits[1], logits[2], dim=0).item()
     assert cos > 0.9995, cos

@@ -20,6 +20,7 @@ def main():
                        sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=2048, max_model_len=2048,
                                              long_prefill_chunk=2048),
                        parallel=ParallelConfig(tp=tp, ep=ep, backend=backend,
+                                               ep_a2a_min_tokens=int(os.environ.get("DLI_TEST_EP_A2A", "2048")),
                                                custom_all_reduce=os.environ.get("DLI_NO_CUSTOM_AR") != "1"), device="cuda",
                        graph_batch_sizes=(4, 8),
                        async_scheduling={"0": False, "1": True}.get(os.environ.get("DLI_TEST_ASYNC", ""), None))
@@ -34,6 +35,7 @@ def main():
             "mixed_graph_steps": eng.runner.stats["mixed_graph_steps"], "eager_steps": eng.runner.stats["eager_steps"],
             "custom_ar": bool(ctx is not None and ctx.custom_ar is not None),
             "overlap_calls": RowParallelLinear.overlap_calls - warm_calls, "overlap_calls_at_warmup": warm_calls, "selftest": eng.runner.selftest,
+            "a2a_calls": ctx.comm["a2a_calls"] if ctx is not None else 0,
             "device_backend": job_info().get("device_backend"), "tuning_source": (job_info().get("tp_group_tuning") or {}).get("source")}
     eng.shutdown()
     join_children()
