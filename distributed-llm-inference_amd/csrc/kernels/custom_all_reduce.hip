@@ -16,7 +16,8 @@
 //
 // Protocol per call (all inside one launch, so the op is hipGraph-capturable; the per-block epoch
 // counter lives in device memory and advances by itself on every replay):
-//   1. copy my input into my staging buffer (peers never read torch-allocator memory);
+//   1. copy my input into my staging buffer (peers never read torch-allocator memory) — skipped when the input IS the
+//      staging buffer: the row-parallel GEMMs write their output there (ar_staging_tensor);
 //   2. barrier "start":  every block tells the same block of every peer "my staging is written";
 //   3. reduce (one-shot → out; two-shot → my slice of my result buffer, barrier "mid", gather → out);
 //   4. barrier "end": nobody may overwrite staging/result before every peer has finished reading.
@@ -145,7 +146,10 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers p, int rank,
   const bf16x8* src = reinterpret_cast<const bf16x8*>(in);
   bf16x8* mine = reinterpret_cast<bf16x8*>(p.staging[rank]);
 
-  for (int64_t i = tid; i < n_vec; i += stride) mine[i] = src[i];
+  // input already IN my staging buffer (the producing GEMM wrote there: RowParallelLinear + ar_staging_tensor) → no copy;
+  // the data is an earlier kernel's, visible to the peers once they pass the barrier
+  if (src != mine)
+    for (int64_t i = tid; i < n_vec; i += stride) mine[i] = src[i];
   mesh_barrier<0>(p, rank, world, flag);
 
   bf16x8* dst = reinterpret_cast<bf16x8*>(out);
@@ -364,6 +368,7 @@ int64_t ep_layout(void* st, int64_t n_cap, int H, int64_t* ids_off, int64_t* wts
   *meta_off = (int64_t)s->max_bytes - kEpMetaBytes;
   return (*wts_off + n_cap * 4 <= *meta_off) ? 0 : -1;
 }
+void* ar_staging_ptr(void* st) { ARState* s = reinterpret_cast<ARState*>(st); return s->peers.staging[s->rank]; }
 void* ep_result_ptr(void* st) { ARState* s = reinterpret_cast<ARState*>(st); return s->peers.result[s->rank]; }
 int64_t ep_max_bytes(void* st) { return (int64_t) reinterpret_cast<ARState*>(st)->max_bytes; }
 

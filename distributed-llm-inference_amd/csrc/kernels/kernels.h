@@ -80,6 +80,7 @@ int launch_broadcast(void* st, void* buf, int64_t bytes, int root, hipStream_t s
 // expert-parallel dispatch / combine over the same IPC buffers (custom_all_reduce.hip)
 int64_t ep_layout(void* st, int64_t n_cap, int H, int64_t* ids_off, int64_t* wts_off, int64_t* meta_off);
 void* ep_result_ptr(void* st);
+void* ar_staging_ptr(void* st);
 int64_t ep_max_bytes(void* st);
 int launch_ep_dispatch(void* st, const void* x, int64_t x_stride, const int* ids, const float* wts, int n, int n_cap, int top_k,
                        int H, int local_experts, int* slot, void* recv_x, int* ids_local, float* w_local, int r_cap,

@@ -56,7 +56,17 @@ Tensor silu_and_mul(const Tensor& x) {
 }
 
 // y = x · Wᵀ (+ bias) for decode-sized x (≤ 16 rows): the weight-streaming kernel in kernels/skinny_gemm.hip
-Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, bool swiglu) {
+// `out` (optional): write the result there instead of a fresh tensor — the row-parallel layers hand in a view of the custom
+// all-reduce's IPC staging buffer, so the reduction reads the GEMM's output in place.
+Tensor take_out(const c10::optional<Tensor>& out, int64_t M, int64_t N, const Tensor& like) {
+  if (!out.has_value()) return at::empty({M, N}, like.options());
+  TORCH_CHECK(out->is_cuda() && out->scalar_type() == at::kBFloat16 && out->dim() == 2 && out->size(0) == M && out->size(1) == N &&
+              out->is_contiguous() && reinterpret_cast<uintptr_t>(out->data_ptr()) % 16 == 0, "out must be a contiguous bf16 [", M, ", ", N, "] GPU tensor");
+  return *out;
+}
+
+Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, bool swiglu,
+                     const c10::optional<Tensor>& out_) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   TORCH_CHECK(M >= 1 && M <= 64, "skinny_linear: 1..64 rows, got ", M);
@@ -72,7 +82,7 @@ Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tenso
   // swiglu: w = [gate; up] (N = 2·I rows), result silu(x·gateᵀ) ⊙ (x·upᵀ) of width I
   TORCH_CHECK(!swiglu || (N % 32 == 0 && b == nullptr), "skinny_linear: swiglu needs N % 32 == 0 and no bias");
   const int64_t n_out = swiglu ? N / 2 : N;
-  Tensor out = at::empty({M, n_out}, x.options());
+  Tensor out = take_out(out_, M, n_out, x);
   dli::launch_skinny_linear(out.data_ptr(), n_out, x.data_ptr(), x.stride(0), w.data_ptr(), b, (int)M, (int)N, (int)K, swiglu,
                             cur_stream(x));
   return out;
@@ -246,7 +256,7 @@ void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
 }
 
 // y = x · Wᵀ on the 256×256×64 tile kernel (gemm256.hip); swiglu: W = [gate; up] rows, y = silu(x·gateᵀ) ⊙ (x·upᵀ)
-Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_splits) {
+Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_splits, const c10::optional<Tensor>& out_) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
@@ -255,7 +265,7 @@ Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_sp
   TORCH_CHECK(K % 64 == 0 && n_out % (swiglu ? 128 : 256) == 0 && N % 2 == 0, "dense_gemm256: unsupported shape N=", N, " K=", K);
   TORCH_CHECK(M >= 1 && M * x.stride(0) * 2 < (int64_t(1) << 32) && N * K * 2 < (int64_t(1) << 32), "dense_gemm256: operand too large");
   TORCH_CHECK(k_splits >= 1 && k_splits <= 32 && k_splits <= K / 64, "dense_gemm256: k_splits must be in [1, min(32, K / 64)]");
-  Tensor out = at::empty({M, n_out}, x.options());
+  Tensor out = take_out(out_, M, n_out, x);
   Tensor ws;                                                  // fp32 partial slabs of the split-K path
   if (k_splits > 1) ws = at::empty({k_splits, M, N}, x.options().dtype(at::kFloat));
   dli::launch_dense_gemm256(swiglu, x.data_ptr(), x.stride(0), w.data_ptr(), out.data_ptr(), n_out, (int)M, (int)K, (int)n_out,
@@ -453,6 +463,14 @@ Tensor ep_moe(int64_t st, const Tensor& x_l, const Tensor& router_logits_l, cons
   return out;
 }
 
+// [rows, cols] bf16 view of THIS rank's IPC staging buffer: a GEMM that writes its output here has "copied its input
+// into the staging buffer" already, and the all-reduce kernels skip that pass when they are handed this very pointer.
+Tensor ar_staging_tensor(int64_t st, int64_t rows, int64_t cols, const Tensor& like) {
+  void* state = reinterpret_cast<void*>(st);
+  TORCH_CHECK(rows >= 1 && cols >= 1 && rows * cols * 2 <= dli::ep_max_bytes(state), "ar_staging_tensor: larger than the staging buffer");
+  return at::from_blob(dli::ar_staging_ptr(state), {rows, cols}, like.options().dtype(at::kBFloat16));
+}
+
 // launch-shape table chosen by the start-up sweep (identical on every rank of the group)
 void ar_set_tuning(int64_t st, const Tensor& thr, const Tensor& algo, const Tensor& blocks, int64_t default_blocks,
                    int64_t one_shot_max_bytes) {
@@ -516,8 +534,9 @@ TORCH_LIBRARY(dli, m) {
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
-  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False) -> Tensor", &skinny_linear);
-  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1) -> Tensor", &dense_gemm256);
+  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None) -> Tensor", &skinny_linear);
+  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None) -> Tensor", &dense_gemm256);
+  m.def("ar_staging_tensor(int state, int rows, int cols, Tensor like) -> Tensor", &ar_staging_tensor);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
         "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale, Tensor? kv_scales=None) -> ()",
         &rope_and_cache);

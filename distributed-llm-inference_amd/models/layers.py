@@ -104,6 +104,7 @@ class RowParallelLinear(nn.Module):
     OVERLAP_MIN_ROWS = int(__import__('os').environ.get('DLI_OVERLAP_MIN_ROWS', '1024'))
     OVERLAP_CHUNKS = int(__import__('os').environ.get('DLI_OVERLAP_CHUNKS', '4'))
     OVERLAP_AR_BLOCKS = int(__import__('os').environ.get('DLI_OVERLAP_AR_BLOCKS', '64'))
+    STAGED_OUTPUT = __import__('os').environ.get('DLI_AR_STAGED_OUTPUT', '1') != '0'   # A/B: GEMM output → IPC staging buffer
     OVERLAP_OK = True          # cleared by ModelRunner.startup_selftest when the pipeline disagrees with the plain path
     overlap_calls = 0          # forward passes that took the pipeline (tests assert the path was taken)
 
@@ -121,6 +122,15 @@ class RowParallelLinear(nn.Module):
         if (self.reduce and self.OVERLAP_OK and self.ctx.distributed and x.is_cuda and x.dim() == 2
                 and x.shape[0] >= self.OVERLAP_MIN_ROWS and self.overlap_capable()):
             return self._forward_overlapped(x, b)
+        ar = self.ctx.custom_ar
+        if (self.reduce and self.STAGED_OUTPUT and ar is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16
+                and self.ctx.distributed and ar.fits(x.shape[0] * self.weight.data.shape[0] * 2)):
+            # the GEMM writes straight into the IPC staging buffer: the reduction kernel has no copy-in pass left
+            y = ops.linear(x, self.weight.data, b, out=ar.staging_tensor(x.shape[0], self.weight.data.shape[0], x))
+            c = self.ctx.comm
+            c["ar_custom_calls"] += 1
+            c["ar_custom_bytes"] += y.numel() * 2
+            return ar.all_reduce(y)
         y = ops.linear(x, self.weight.data, b)
         return self.ctx.all_reduce(y) if self.reduce else y
 

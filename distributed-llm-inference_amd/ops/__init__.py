@@ -244,17 +244,21 @@ def _tile_operand_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
             and x.shape[0] * x.stride(0) * 2 < 2 ** 32 and weight.numel() * 2 < 2 ** 32)
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``x @ weightᵀ + bias``.  Decode-sized GPU inputs take the weight-streaming MFMA kernel
     (``csrc/kernels/skinny_gemm.hip``); above that the start-up measurement (``ops/gemm_plan.py``) says, per layer shape
     and row count, whether the library GEMM (hipBLASLt through torch) or the own 256² tile — with K cut into slices at
-    mid-M — runs; shapes it never measured go to the library."""
+    mid-M — runs; shapes it never measured go to the library.  ``out``: 2-D result buffer to write into (the row-parallel
+    layers pass a view of the all-reduce's IPC staging buffer)."""
     if _skinny_ok(x, weight, 16):
-        return hip().skinny_linear(x, weight, bias, False)
+        return hip().skinny_linear(x, weight, bias, False, out)
     if bias is None and _PLAN.table and x.is_cuda and x.dim() == 2:
         s = _PLAN.splits_for(x.shape[0], weight.shape[0], weight.shape[1], False)
         if s and _tile_operand_ok(x, weight):
-            return hip().dense_gemm256(x, weight, False, s)
+            return hip().dense_gemm256(x, weight, False, s, out)
+    if out is not None:
+        return torch.mm(x, weight.t(), out=out) if bias is None else torch.addmm(bias, x, weight.t(), out=out)
     return torch.nn.functional.linear(x, weight, bias)
 
 

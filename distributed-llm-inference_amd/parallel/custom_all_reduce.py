@@ -113,6 +113,15 @@ class CustomAllReduce:
         return (self.enabled and x.is_cuda and x.dtype == torch.bfloat16 and x.is_contiguous()
                 and 0 < x.numel() * 2 <= self.use_max_bytes and (x.numel() * 2) % 16 == 0 and x.data_ptr() % 16 == 0)
 
+    def fits(self, nbytes: int) -> bool:
+        return self.enabled and 0 < nbytes <= self.use_max_bytes and nbytes % 16 == 0
+
+    def staging_tensor(self, rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+        """``[rows, cols]`` bf16 view of this rank's IPC staging buffer.  A GEMM that writes its output here has done the
+        all-reduce's copy-in pass already (the kernels skip it when they are handed this pointer).  Valid until the next
+        collective of this group writes the buffer: produce → ``all_reduce`` → done."""
+        return self.lib.ar_staging_tensor(self.state, rows, cols, like)
+
     def all_reduce(self, x: torch.Tensor, algo: int = 0, blocks: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
         """Out-of-place sum over the TP group (``algo``: 0 tuned/auto, 1 one-shot, 2 two-shot; ``blocks``: 0 tuned, else
         a cap on the workgroups — every rank must pass the same value)."""
