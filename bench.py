@@ -251,7 +251,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    layout = launch.Layout.from_env(args.gpus, args.tp, args.ep)
+    layout = launch.Layout.from_env(args.gpus, args.tp, args.ep if args.emulate_tp <= 1 else 1)   # emulated rank: ep lives in its context
     # stdout carries exactly ONE line: the JSON of rank 0.  Libraries write there too (gloo prints its connection
     # messages to stdout from C++), so the real stdout is kept aside and file descriptor 1 joins stderr for the run.
     sys.stdout.flush()

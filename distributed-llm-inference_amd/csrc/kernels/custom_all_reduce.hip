@@ -184,6 +184,78 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers p, int rank,
   if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
 }
 
+// Sequence-parallel form of "all-reduce → residual add → RMSNorm" (the pair that follows every row-parallel GEMM of a
+// transformer layer), in ONE kernel on the two-shot protocol: rank r reduces ROWS [r·rpr, (r+1)·rpr) of the partial sums
+// from all peers' staging buffers, adds its rows of the residual stream (and writes them back: from here on every rank
+// carries the residual of its own rows only), normalises them and publishes the normalised rows in its result buffer; after
+// the mid barrier every rank gathers all rows.  Against all-reduce + a separate fused_add_rms_norm over all T rows on every
+// rank, the norm runs on T / world rows (one TP = 8 rank of Llama-3-70B spends 8.3 % of a saturated step in that kernel:
+// profiles/tp8_shard_emulation_r3.md) and the [T, H] intermediate never exists.
+// The partial sums must already BE in the staging buffer (the producing GEMM writes there: ar_staging_tensor) — an earlier
+// kernel's data, visible to every peer after any block's start barrier.  Row → block mapping (row of a slice ≡ block index
+// mod grid) is the same in the reduce and the gather phase on every rank, so the per-block mid barrier orders exactly the
+// rows a block gathers.  One 512-thread block holds a row of up to 8192 elements in registers between the two passes.
+// Numerics mirror the unfused pair: the sum is rounded to bf16 before the residual add.
+template <int W>
+__global__ __launch_bounds__(kThreads) void all_reduce_add_norm_kernel(Peers p, int rank, int world_rt, uint16_t* __restrict__ residual,
+                                                                       const uint16_t* __restrict__ weight, float eps,
+                                                                       uint16_t* __restrict__ out, int T, int H) {
+  const int world = W > 0 ? W : world_rt;
+  Signal* self = p.signal[rank];
+  const uint32_t flag = self->epoch[blockIdx.x] + 1;
+  __shared__ float red[kThreads / 64];
+  mesh_barrier<0>(p, rank, world, flag);
+  const int vpr = H >> 3;
+  const int rpr = (T + world - 1) / world;
+  const int r_end = min((rank + 1) * rpr, T);
+  bf16x8* mine = reinterpret_cast<bf16x8*>(p.result[rank]);
+  for (int row = rank * rpr + blockIdx.x; row < r_end; row += gridDim.x) {
+    float vals[2][8];
+    bf16x8 gw[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = threadIdx.x + i * kThreads;
+      if (v < vpr) {
+        const bf16x8 s = reduce_at<W>(p, world, (int64_t)row * vpr + v);
+        gw[i] = *reinterpret_cast<const bf16x8*>(weight + v * 8);
+        bf16x8* rp = reinterpret_cast<bf16x8*>(residual + (int64_t)row * H) + v;
+        const bf16x8 r = *rp;
+        bf16x8 nr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = bf2f((uint16_t)s[j]) + bf2f((uint16_t)r[j]);
+          vals[i][j] = f;
+          nr[j] = (short)f2bf(f);
+          ss += f * f;
+        }
+        *rp = nr;
+      }
+    }
+    const float inv = rsqrtf(block_sum<kThreads>(ss, red) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int v = threadIdx.x + i * kThreads;
+      if (v < vpr) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(vals[i][j] * inv * bf2f((uint16_t)gw[i][j]));
+        mine[(int64_t)row * vpr + v] = o;
+      }
+    }
+  }
+  mesh_barrier<1>(p, rank, world, flag);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out);
+  for (int q = 0; q < world; ++q) {
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(p.result[q]);
+    const int q_end = min((q + 1) * rpr, T);
+    for (int row = q * rpr + blockIdx.x; row < q_end; row += gridDim.x)
+      for (int v = threadIdx.x; v < vpr; v += kThreads) dst[(int64_t)row * vpr + v] = src[(int64_t)row * vpr + v];
+  }
+  mesh_barrier<2>(p, rank, world, flag);
+  if (threadIdx.x == 0) self->epoch[blockIdx.x] = flag;
+}
+
 // All-gather with the same protocol: out[r][i] = in_r[i] (rank-major).  Used for the vocab-parallel logits so
 // that a TP decode graph contains no library collective at all.
 __global__ __launch_bounds__(kThreads) void all_gather_kernel(Peers p, int rank, int world, const uint16_t* __restrict__ in,
@@ -514,6 +586,25 @@ int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int al
     launch_ar<true>(s, blocks, in, out, n_vec, stream);
   else
     launch_ar<false>(s, blocks, in, out, n_vec, stream);
+  return 0;
+}
+
+// staged: the partial sums [T, H] live in this rank's staging buffer.  blocks: same value on every rank.
+int launch_all_reduce_add_norm(void* st, void* residual, const void* weight, float eps, void* out, int T, int H, int blocks,
+                               hipStream_t stream) {
+  ARState* s = reinterpret_cast<ARState*>(st);
+  if (T <= 0 || H % 8 != 0 || H > 16 * kThreads || (size_t)T * H * 2 > s->max_bytes) return -1;
+  const int rpr = (T + s->world - 1) / s->world;
+  blocks = std::max(1, std::min({blocks > 0 ? blocks : 64, rpr, kMaxBlocks}));
+  uint16_t* r = (uint16_t*)residual;
+  const uint16_t* w = (const uint16_t*)weight;
+  uint16_t* o = (uint16_t*)out;
+  switch (s->world) {
+    case 2: hipLaunchKernelGGL(all_reduce_add_norm_kernel<2>, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, 2, r, w, eps, o, T, H); break;
+    case 4: hipLaunchKernelGGL(all_reduce_add_norm_kernel<4>, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, 4, r, w, eps, o, T, H); break;
+    case 8: hipLaunchKernelGGL(all_reduce_add_norm_kernel<8>, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, 8, r, w, eps, o, T, H); break;
+    default: hipLaunchKernelGGL(all_reduce_add_norm_kernel<0>, dim3(blocks), dim3(kThreads), 0, stream, s->peers, s->rank, s->world, r, w, eps, o, T, H);
+  }
   return 0;
 }
 

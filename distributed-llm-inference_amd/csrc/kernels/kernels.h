@@ -75,6 +75,8 @@ int ar_set_tuning(void* st, int n, const int64_t* thr, const int* algo, const in
 int ar_error(void* st);
 int ar_error_async(void* st, void* pinned_dst4, hipStream_t stream);
 int launch_all_reduce(void* st, const void* in, void* out, int64_t bytes, int algo, int blocks, hipStream_t stream);
+int launch_all_reduce_add_norm(void* st, void* residual, const void* weight, float eps, void* out, int T, int H, int blocks,
+                               hipStream_t stream);
 int launch_all_gather(void* st, const void* in, void* out, int64_t bytes, hipStream_t stream);
 int launch_broadcast(void* st, void* buf, int64_t bytes, int root, hipStream_t stream);
 // expert-parallel dispatch / combine over the same IPC buffers (custom_all_reduce.hip)

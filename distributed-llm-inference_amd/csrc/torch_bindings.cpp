@@ -323,7 +323,7 @@ void moe_experts_forward(const Tensor& x, const Tensor& ids, const Tensor& wts, 
 
 // ---- MoE: route → align → grouped GEMM (SwiGLU epilogue) → grouped GEMM (weighted scatter) → sum ----
 Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13, const Tensor& w2, int64_t top_k,
-                 int64_t expert_offset, int64_t tile_rows) {
+                 int64_t expert_offset, int64_t tile_rows, const c10::optional<Tensor>& out_) {
   check_bf16_rows(x, "x");
   TORCH_CHECK(router_logits.is_cuda() && router_logits.scalar_type() == at::kBFloat16 && router_logits.dim() == 2,
               "router_logits must be a 2-D bfloat16 GPU tensor");
@@ -346,7 +346,7 @@ Tensor fused_moe(const Tensor& x, const Tensor& router_logits, const Tensor& w13
   const int64_t max_tiles = capacity / TR;
   Tensor ids = at::empty({n}, i32), wts = at::empty({n}, x.options().dtype(at::kFloat));
   Tensor sorted = at::empty({capacity}, i32), tile_expert = at::empty({max_tiles}, i32), meta = at::empty({2}, i32);
-  Tensor out = at::empty({T, H}, x.options());
+  Tensor out = take_out(out_, T, H, x);
   if (T <= std::min<int64_t>(g_moe_skinny_max_t, 128) && I % 128 == 0 && tile_rows == 0) {
     // Decode-sized batch: an expert sees ≤ 16 rows (at T ≤ 32 and 2-of-8 routing: nearly always; more rows cost an
     // extra pass over that expert's weights from cache), so both projections are pure weight streams — the
@@ -463,6 +463,22 @@ Tensor ep_moe(int64_t st, const Tensor& x_l, const Tensor& router_logits_l, cons
   return out;
 }
 
+// all-reduce(staged partial sums) → residual add (this rank's rows, in place) → RMSNorm → all rows gathered into `out`
+void ar_all_reduce_add_norm(int64_t st, const Tensor& staged, Tensor residual, const Tensor& weight, double eps, Tensor out,
+                            int64_t blocks) {
+  void* state = reinterpret_cast<void*>(st);
+  TORCH_CHECK(staged.data_ptr() == dli::ar_staging_ptr(state), "all_reduce_add_norm: the input must be the staging view (ar_staging_tensor)");
+  TORCH_CHECK(staged.dim() == 2 && residual.is_cuda() && out.is_cuda() && weight.is_cuda() && residual.scalar_type() == at::kBFloat16 &&
+              out.scalar_type() == at::kBFloat16 && weight.scalar_type() == at::kBFloat16 && residual.is_contiguous() &&
+              out.is_contiguous() && weight.is_contiguous());
+  const int64_t T = staged.size(0), H = staged.size(1);
+  TORCH_CHECK(residual.size(0) == T && residual.size(1) == H && out.size(0) == T && out.size(1) == H && weight.numel() == H);
+  TORCH_CHECK(reinterpret_cast<uintptr_t>(residual.data_ptr()) % 16 == 0 && reinterpret_cast<uintptr_t>(out.data_ptr()) % 16 == 0);
+  const int rc = dli::launch_all_reduce_add_norm(state, residual.data_ptr(), weight.data_ptr(), (float)eps, out.data_ptr(), (int)T, (int)H,
+                                                 (int)blocks, cur_stream(residual));
+  TORCH_CHECK(rc == 0, "all_reduce_add_norm: [", T, ", ", H, "] not supported");
+}
+
 // [rows, cols] bf16 view of THIS rank's IPC staging buffer: a GEMM that writes its output here has "copied its input
 // into the staging buffer" already, and the all-reduce kernels skip that pass when they are handed this very pointer.
 Tensor ar_staging_tensor(int64_t st, int64_t rows, int64_t cols, const Tensor& like) {
@@ -511,7 +527,7 @@ void ar_all_gather(int64_t st, const Tensor& inp, Tensor out) {
 }  // namespace
 
 TORCH_LIBRARY(dli, m) {
-  m.def("fused_moe(Tensor x, Tensor router_logits, Tensor w13, Tensor w2, int top_k, int expert_offset, int tile_rows=0) -> Tensor",
+  m.def("fused_moe(Tensor x, Tensor router_logits, Tensor w13, Tensor w2, int top_k, int expert_offset, int tile_rows=0, Tensor? out=None) -> Tensor",
         &fused_moe);
   m.def("ar_alloc(int bytes, bool uncached) -> int", &ar_alloc);
   m.def("ar_free(int ptr) -> ()", &ar_free);
@@ -537,6 +553,8 @@ TORCH_LIBRARY(dli, m) {
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None) -> Tensor", &skinny_linear);
   m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None) -> Tensor", &dense_gemm256);
   m.def("ar_staging_tensor(int state, int rows, int cols, Tensor like) -> Tensor", &ar_staging_tensor);
+  m.def("ar_all_reduce_add_norm(int state, Tensor staged, Tensor(a!) residual, Tensor weight, float eps, Tensor(b!) out, int blocks=0) -> ()",
+        &ar_all_reduce_add_norm);
   m.def("rope_and_cache(Tensor(a!) qkv, Tensor positions, Tensor? cos_sin, Tensor slot_mapping, Tensor(b!) k_cache, "
         "Tensor(c!) v_cache, int num_heads, int num_kv_heads, float k_scale, float v_scale, Tensor? kv_scales=None) -> ()",
         &rope_and_cache);

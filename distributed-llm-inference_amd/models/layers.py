@@ -88,6 +88,40 @@ class ColumnParallelLinear(nn.Module):
         return ops.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
 
 
+class Partial:
+    """A row-parallel result whose reduction is still owed (sequence-parallel steps, ``ParallelContext.sp_step``): the
+    layer that consumes it fuses the reduction with its residual add + RMSNorm (``add_norm``).
+    ``kind == "reduce"``: ``t`` = this rank's partial sums ``[T, H]`` (in the IPC staging buffer; a plain tensor under
+    emulation); ``kind == "rows"``: ``t`` = the finished rows of THIS rank's slice only (expert-parallel dispatch path)."""
+    __slots__ = ("kind", "t")
+
+    def __init__(self, kind: str, t: torch.Tensor):
+        self.kind, self.t = kind, t
+
+
+def add_norm(h, residual: torch.Tensor, weight: torch.Tensor, eps: float, ctx: ParallelContext) -> torch.Tensor:
+    """``residual += h; return rmsnorm(residual) * weight`` — for a plain tensor the in-place kernel, for a ``Partial`` the
+    sequence-parallel form: reduce / add / normalise this rank's rows, then gather all rows."""
+    if not isinstance(h, Partial):
+        ops.fused_add_rms_norm(h, residual, weight, eps)
+        return h
+    T = residual.shape[0]
+    lo, hi, per = ctx.sp_rows(T)
+    if h.kind == "reduce" and not ctx.emulated:
+        ctx.comm["ar_custom_calls"] += 1
+        ctx.comm["ar_custom_bytes"] += h.t.numel() * 2
+        return ctx.custom_ar.all_reduce_add_norm(h.t, residual, weight, eps)
+    if h.kind == "reduce":                                   # emulated rank: same bytes moved, norm on the rank's rows only
+        out = ctx.all_reduce(h.t)
+        ops.fused_add_rms_norm(out[lo:hi], residual[lo:hi], weight, eps)
+        return out
+    rows = h.t[:hi - lo]
+    ops.fused_add_rms_norm(rows, residual[lo:hi], weight, eps)
+    if rows.shape[0] < per:
+        rows = torch.cat([rows, rows.new_zeros(per - rows.shape[0], rows.shape[1])])
+    return ctx.all_gather_rows(rows)[:T]
+
+
 class RowParallelLinear(nn.Module):
     """``y = all_reduce(x_shard @ W_shardᵀ)``.
 
@@ -116,9 +150,16 @@ class RowParallelLinear(nn.Module):
         self.weight = Weight((out_features, in_features), 1, ctx, dtype, device)
         self.bias = Weight((out_features,), None, ctx, dtype, device) if bias else None
 
-    def forward(self, x):
+    def forward(self, x, defer: bool = False):
+        """``defer`` (sequence-parallel step): return the un-reduced partial sums as a ``Partial`` — written straight into
+        the IPC staging buffer — for the consumer's fused reduce + add + norm."""
         # the bias must be added once, not tp times: only rank 0 adds it before the reduction
         b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
+        if defer and self.reduce and self.ctx.sp_step:
+            ar = self.ctx.custom_ar
+            N = self.weight.data.shape[0]
+            out = None if self.ctx.emulated else ar.staging_tensor(x.shape[0], N, x)
+            return Partial("reduce", ops.linear(x, self.weight.data, b, out=out))
         if (self.reduce and self.OVERLAP_OK and self.ctx.distributed and x.is_cuda and x.dim() == 2
                 and x.shape[0] >= self.OVERLAP_MIN_ROWS and self.overlap_capable()):
             return self._forward_overlapped(x, b)

@@ -29,8 +29,8 @@ from .. import ops
 from ..config import ModelConfig
 from ..ops.reference import attention_scale, build_cos_sin_cache
 from ..parallel.state import ParallelContext
-from .layers import (ColumnParallelLinear, ParallelLMHead, ReplicatedLinear, RowParallelLinear,
-                     VocabParallelEmbedding, Weight)
+from .layers import (ColumnParallelLinear, ParallelLMHead, Partial, ReplicatedLinear, RowParallelLinear,
+                     VocabParallelEmbedding, Weight, add_norm)
 
 
 _EP_DEBUG = __import__("os").environ.get("DLI_DEBUG_EP_CHECK") == "1"
@@ -116,7 +116,7 @@ class Attention(nn.Module):
                            self.hq, self.hkv, self.d, self.k_scale, self.v_scale, self.kv_scales)
         a = ops.paged_attention(qkv, k_cache, v_cache, meta, self.hq, self.hkv, self.d, self.scale,
                                 self.k_scale, self.v_scale, kv_scales=self.kv_scales)
-        return self.o(a)
+        return self.o(a, defer=True)
 
 
 class SwiGLUMLP(nn.Module):
@@ -127,7 +127,7 @@ class SwiGLUMLP(nn.Module):
         self.down = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, ctx, dtype, device)
 
     def forward(self, h):
-        return self.down(ops.linear_swiglu(h, self.gate_up.weight.data))
+        return self.down(ops.linear_swiglu(h, self.gate_up.weight.data), defer=True)
 
 
 class MoEBlock(nn.Module):
@@ -158,6 +158,9 @@ class MoEBlock(nn.Module):
         logits = self.router(h)
         if _EP_DEBUG and self.ctx.tp_size > 1 and not torch.cuda.is_current_stream_capturing():
             _ep_consistency_check(self.ctx, h, logits)
+        if ctx.sp_step:                                      # the consumer's fused reduce + add + norm takes the partial sums
+            stage = None if ctx.emulated else ctx.custom_ar.staging_tensor(h.shape[0], h.shape[1], h)
+            return Partial("reduce", ops.fused_moe(h, logits, self.w13.data, self.w2.data, self.top_k, self.expert_offset, out=stage))
         out = ops.fused_moe(h, logits, self.w13.data, self.w2.data, self.top_k, self.expert_offset)
         return self.ctx.all_reduce(out)
 
@@ -192,10 +195,16 @@ class MoEBlock(nn.Module):
             out_l = ar.ep_moe(hl, self.router(hl), self.w13.data, self.w2.data, k, per * k)
             ctx.comm["a2a_calls"] += 2
             ctx.comm["a2a_bytes"] += 2 * hl.shape[0] * k * H * hl.element_size()
+            if ctx.sp_step and step >= T:                                    # one call covers the step: the rows stay local,
+                return Partial("rows", out_l)                                # the consumer normalises them, then gathers
             if out_l.shape[0] < per:                                         # the last rank's slice may be short
                 out_l = torch.cat([out_l, out_l.new_zeros(per - out_l.shape[0], H)])
             outs.append(ctx.all_gather_rows(out_l)[:Tp])
-        return outs[0] if len(outs) == 1 else torch.cat(outs)
+        full = outs[0] if len(outs) == 1 else torch.cat(outs)
+        if ctx.sp_step:                                                      # several calls: hand over this rank's rows of the result
+            lo, hi, _ = ctx.sp_rows(T)
+            return Partial("rows", full[lo:hi].contiguous())
+        return full
 
     def _forward_all_to_all_reference(self, h):
         """CPU reference of the dispatch (gloo; the multi-process CPU tests): same slicing, same owner computation, the
@@ -243,14 +252,16 @@ class DecoderLayer(nn.Module):
         self.mlp = MoEBlock(cfg, ctx, dtype, device) if cfg.num_experts > 0 else SwiGLUMLP(cfg, ctx, dtype, device)
 
     def forward(self, h, residual, meta, kv, cos_sin):
+        ctx = self.attn.o.ctx
         if residual is None:
             residual = h
             h = ops.rms_norm(h, self.input_norm.data, self.eps)
         else:
-            ops.fused_add_rms_norm(h, residual, self.input_norm.data, self.eps)
+            h = add_norm(h, residual, self.input_norm.data, self.eps, ctx)   # h: the previous layer's MLP output, maybe un-reduced
         h = self.attn(h, meta, kv, cos_sin)
-        _rank_check(self.attn.o.ctx, "attn-out", h)
-        ops.fused_add_rms_norm(h, residual, self.post_norm.data, self.eps)
+        if not isinstance(h, Partial):
+            _rank_check(ctx, "attn-out", h)
+        h = add_norm(h, residual, self.post_norm.data, self.eps, ctx)
         h = self.mlp(h)
         return h, residual
 
@@ -275,11 +286,18 @@ class LlamaForCausalLM(nn.Module):
     def forward(self, input_ids: torch.Tensor, meta, kv_caches) -> torch.Tensor:
         h = self.embed(input_ids)
         _rank_check(self.ctx, "embed", h)
+        # one decision for the whole pass: with sequence-parallel norms every rank keeps the residual of its own rows only
+        self.ctx.sp_step = self.ctx.sp_wanted(h.shape[0], h.shape[1], h.is_cuda) and not self._overlap_takes(h.shape[0])
         residual = None
         for layer, kv in zip(self.layers, kv_caches):
             h, residual = layer(h, residual, meta, kv, self.cos_sin)
-        ops.fused_add_rms_norm(h, residual, self.final_norm.data, self.cfg.rms_eps)
+        h = add_norm(h, residual, self.final_norm.data, self.cfg.rms_eps, self.ctx)
+        self.ctx.sp_step = False
         return h
+
+    def _overlap_takes(self, T: int) -> bool:
+        """Steps the GEMM / all-reduce pipeline serves (it won the start-up timing on this system) keep the plain norms."""
+        return RowParallelLinear.OVERLAP_OK and self.ctx.distributed and T >= RowParallelLinear.OVERLAP_MIN_ROWS
 
     def compute_logits(self, h: torch.Tensor) -> torch.Tensor:
         return self.lm_head(h)

@@ -401,9 +401,13 @@ def copy_pages(cache: torch.Tensor, pairs: torch.Tensor) -> None:
 
 
 def fused_moe(x: torch.Tensor, router_logits: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int,
-              expert_offset: int = 0) -> torch.Tensor:
-    """Mixtral MoE block for the experts held by this rank (partial sum; caller all-reduces)."""
+              expert_offset: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Mixtral MoE block for the experts held by this rank (partial sum; caller all-reduces).  ``out``: result buffer."""
     from . import moe as _moe
     if x.is_cuda and os.environ.get('DLI_MOE_REF') != '1' and _moe.hip_moe_supported(x, w13):
-        return _moe.fused_moe_hip(x, router_logits, w13, w2, top_k, expert_offset)
-    return ref.moe_ref(x, router_logits, w13, w2, top_k, expert_offset)
+        return _moe.fused_moe_hip(x, router_logits, w13, w2, top_k, expert_offset, out)
+    res = ref.moe_ref(x, router_logits, w13, w2, top_k, expert_offset)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res

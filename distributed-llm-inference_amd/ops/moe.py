@@ -15,6 +15,6 @@ def hip_moe_supported(x: torch.Tensor, w13: torch.Tensor) -> bool:
     return True
 
 
-def fused_moe_hip(x, router_logits, w13, w2, top_k, expert_offset):
+def fused_moe_hip(x, router_logits, w13, w2, top_k, expert_offset, out=None):
     from . import hip
-    return hip().fused_moe(x.contiguous(), router_logits.contiguous(), w13, w2, top_k, expert_offset)
+    return hip().fused_moe(x.contiguous(), router_logits.contiguous(), w13, w2, top_k, expert_offset, 0, out)

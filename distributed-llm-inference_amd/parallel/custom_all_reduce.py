@@ -122,6 +122,18 @@ class CustomAllReduce:
         collective of this group writes the buffer: produce → ``all_reduce`` → done."""
         return self.lib.ar_staging_tensor(self.state, rows, cols, like)
 
+    @property
+    def one_shot_max_bytes(self) -> int:
+        return int(self.tuning.get("one_shot_up_to_bytes", 256 << 10)) if self.tuning else (256 << 10)
+
+    def all_reduce_add_norm(self, staged: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+        """Sequence-parallel all-reduce → residual add → RMSNorm in one kernel (``all_reduce_add_norm_kernel``).  ``staged``:
+        the partial sums, a ``staging_tensor`` view.  ``residual`` is updated IN PLACE for this rank's rows only
+        (rows ``[rank·⌈T/world⌉, …)``): afterwards its other rows are stale by design.  Returns the normalised ``[T, H]``."""
+        out = torch.empty_like(residual)
+        self.lib.ar_all_reduce_add_norm(self.state, staged, residual, weight, eps, out, min(64, self.block_cap))
+        return out
+
     def all_reduce(self, x: torch.Tensor, algo: int = 0, blocks: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
         """Out-of-place sum over the TP group (``algo``: 0 tuned/auto, 1 one-shot, 2 two-shot; ``blocks``: 0 tuned, else
         a cap on the workgroups — every rank must pass the same value)."""

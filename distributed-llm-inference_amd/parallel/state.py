@@ -38,6 +38,12 @@ class ParallelContext:
     # same bytes — the rank's GEMM / attention shapes, kernel count and host work per step are the real ones, the link
     # time is not.  Measures what one GPU of an 8-GPU replica has to do, on the one GPU there is.
     emulated: bool = False
+    # Sequence-parallel norms (set per forward pass by the model, see `sp_wanted`): the reductions that follow the
+    # row-parallel GEMMs are fused with the residual add + RMSNorm and run on this rank's T / tp rows only
+    # (`CustomAllReduce.all_reduce_add_norm`); every rank then carries the residual stream of ITS rows only, so all
+    # add-norm sites of one forward pass must take the same path — this flag is that agreement.
+    sp_step: bool = False
+    sp_ok: bool = os.environ.get("DLI_SP_NORM", "1") != "0"      # cleared by the start-up self-test on a mismatch
     # calls / bytes per collective kind and path since start-up (host-side counts; a hipGraph replay adds the
     # counts recorded at its capture, see ModelRunner)
     comm: dict = field(default_factory=lambda: {"ar_custom_calls": 0, "ar_custom_bytes": 0, "ar_lib_calls": 0,
@@ -64,6 +70,24 @@ class ParallelContext:
         if self.tp_size == 1 or self.group is None:
             return "none"
         return dist.get_backend(self.group)
+
+    def sp_wanted(self, T: int, H: int, on_gpu: bool) -> bool:
+        """Fused sequence-parallel reduce + add + norm for a forward pass of ``T`` rows?  Needs the custom kernels (the
+        GEMMs write their partial sums into the IPC staging buffer), a message in the two-shot regime (one-shot
+        all-reduce + a whole-batch norm is faster for decode-sized steps) and rows that fit a workgroup's registers."""
+        if not (self.sp_ok and on_gpu and self.tp_size > 1 and H % 8 == 0 and H <= 8192 and T >= self.tp_size):
+            return False
+        nbytes = T * H * 2
+        if self.emulated:
+            return nbytes > (256 << 10)
+        ar = self.custom_ar
+        return ar is not None and ar.fits(nbytes) and nbytes > ar.one_shot_max_bytes
+
+    def sp_rows(self, T: int):
+        """This rank's row range of a sequence-parallel step."""
+        per = (T + self.tp_size - 1) // self.tp_size
+        lo = min(self.tp_rank * per, T)
+        return lo, min(lo + per, T), per
 
     def _custom_only(self, x: torch.Tensor) -> bool:
         ar = self.custom_ar
