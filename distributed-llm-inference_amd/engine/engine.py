@@ -260,6 +260,7 @@ class LLMEngine:
             self.runner.calibrate_kv_scales(ids if ids is not None and len(ids) >= 16 else None)
         self.runner.tune_gemms()                             # measured GEMM dispatch: the captured steps hold its choices
         self.runner.selftest_overlap()                       # decides what the captured steps will contain
+        self.runner.selftest_sp_norm()                       # (same: sequence-parallel reduce + add + norm, or the plain norms)
         if capture_graphs:
             self.runner.capture_all()
         self.runner.startup_selftest()

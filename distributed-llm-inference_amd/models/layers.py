@@ -107,16 +107,17 @@ def add_norm(h, residual: torch.Tensor, weight: torch.Tensor, eps: float, ctx: P
         return h
     T = residual.shape[0]
     lo, hi, per = ctx.sp_rows(T)
+    ctx.comm["sp_norm_calls"] += 1
     if h.kind == "reduce" and not ctx.emulated:
         ctx.comm["ar_custom_calls"] += 1
         ctx.comm["ar_custom_bytes"] += h.t.numel() * 2
         return ctx.custom_ar.all_reduce_add_norm(h.t, residual, weight, eps)
-    if h.kind == "reduce":                                   # emulated rank: same bytes moved, norm on the rank's rows only
-        out = ctx.all_reduce(h.t)
-        ops.fused_add_rms_norm(out[lo:hi], residual[lo:hi], weight, eps)
-        return out
-    rows = h.t[:hi - lo]
-    ops.fused_add_rms_norm(rows, residual[lo:hi], weight, eps)
+    if h.kind == "reduce":                                   # emulated rank: a same-bytes stand-in for the reads of the peers'
+        rows = ctx.all_reduce(h.t)[lo:hi]                    # partial sums, the norm on this rank's rows, the gather's writes
+    else:
+        rows = h.t[:hi - lo]
+    if hi > lo:
+        ops.fused_add_rms_norm(rows, residual[lo:hi], weight, eps)
     if rows.shape[0] < per:
         rows = torch.cat([rows, rows.new_zeros(per - rows.shape[0], rows.shape[1])])
     return ctx.all_gather_rows(rows)[:T]

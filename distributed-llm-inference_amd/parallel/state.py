@@ -47,7 +47,7 @@ class ParallelContext:
     # calls / bytes per collective kind and path since start-up (host-side counts; a hipGraph replay adds the
     # counts recorded at its capture, see ModelRunner)
     comm: dict = field(default_factory=lambda: {"ar_custom_calls": 0, "ar_custom_bytes": 0, "ar_lib_calls": 0,
-                                                "ar_lib_bytes": 0, "ag_calls": 0, "ag_bytes": 0, "a2a_calls": 0,
+                                                "ar_lib_bytes": 0, "ag_calls": 0, "ag_bytes": 0, "a2a_calls": 0, "sp_norm_calls": 0,
                                                 "a2a_bytes": 0, "bcast_calls": 0, "bcast_bytes": 0})
 
     @property
@@ -81,7 +81,8 @@ class ParallelContext:
         if self.emulated:
             return nbytes > (256 << 10)
         ar = self.custom_ar
-        return ar is not None and ar.fits(nbytes) and nbytes > ar.one_shot_max_bytes
+        floor = int(os.environ.get("DLI_SP_MIN_BYTES", "0")) or ar.one_shot_max_bytes if ar is not None else 0
+        return ar is not None and ar.enabled and ar.fits(nbytes) and nbytes > floor
 
     def sp_rows(self, T: int):
         """This rank's row range of a sequence-parallel step."""

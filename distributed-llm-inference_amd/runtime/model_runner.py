@@ -920,6 +920,74 @@ class ModelRunner:
                     self._gate_overlap_by_time(layer, x, res["overlapped_row_parallel"])
         return res
 
+    @torch.inference_mode()
+    def selftest_sp_norm(self) -> dict:
+        """Sequence-parallel reduce + add + norm kernel (``ParallelContext.sp_step``) against all-reduce →
+        ``fused_add_rms_norm`` on random data of a large step's shape, on every rank; then both are timed and the fused
+        path stays on only if it is not slower.  Runs before graph capture, like ``selftest_overlap``."""
+        res, ctx = self.selftest, self.ctx
+        mc = self.model.cfg
+        H = mc.hidden_size
+        rows = min(self.max_T, 2048)
+        if not self.on_gpu or ctx.tp_size == 1 or not ctx.sp_ok:
+            return res
+        if ctx.emulated or not ctx.sp_wanted(rows, H, True):
+            res["sp_add_norm"] = {"ok": None, "skipped": "emulated rank" if ctx.emulated else "no custom all-reduce / step too small"}
+            return res
+        ar, eps = ctx.custom_ar, mc.rms_eps
+        lo, hi, _ = ctx.sp_rows(rows)
+        try:
+            g = torch.Generator(device=self.device).manual_seed(977 + ctx.tp_rank)
+            y = (torch.randn(rows, H, generator=g, device=self.device) * 0.5).to(self.dtype)
+            g0 = torch.Generator(device=self.device).manual_seed(55)
+            resid = torch.randn(rows, H, generator=g0, device=self.device).to(self.dtype)
+            w = (1 + 0.1 * torch.randn(H, generator=g0, device=self.device)).to(self.dtype)
+
+            def plain(r):
+                o = ctx.all_reduce(y.clone())
+                ops.fused_add_rms_norm(o, r, w, eps)
+                return o
+
+            def fused(r):
+                st = ar.staging_tensor(rows, H, y)
+                st.copy_(y)
+                return ar.all_reduce_add_norm(st, r, w, eps)
+            r0, r1 = resid.clone(), resid.clone()
+            want, got = plain(r0).float(), fused(r1).float()
+            torch.cuda.synchronize()
+            diff = max(float((want - got).abs().max()), float((r0[lo:hi].float() - r1[lo:hi].float()).abs().max()))
+            scale = float(want.abs().max())
+            ok = bool(diff == diff and diff <= 3e-2 * scale + 1e-3)
+            res["sp_add_norm"] = {"max_abs_diff": round(diff, 6), "scale": round(scale, 4), "rows": rows}
+            if ok:
+                def timed(fn, iters=10):
+                    r = resid.clone()
+                    fn(r)
+                    torch.cuda.synchronize()
+                    ctx.barrier()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        fn(r)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) * 1e3 / iters
+                t = ctx.broadcast_object((timed(plain), timed(fused)), src=0)
+                res["sp_add_norm"].update(plain_us=round(t[0], 1), fused_us=round(t[1], 1))
+                if os.environ.get("DLI_SP_FORCE") != "1" and t[1] > 1.03 * t[0]:
+                    res["sp_add_norm"]["enabled"] = False
+                    ctx.sp_ok = False
+        except Exception as e:
+            ok = False
+            res["sp_add_norm"] = {"error": f"{type(e).__name__}: {e}"}
+        ok = self._vote(ok)
+        res["sp_add_norm"]["ok"] = ok
+        if not ok:
+            ctx.sp_ok = False
+            print(f"[dli_amd] sequence-parallel add-norm disabled by the start-up self-test: {res['sp_add_norm']}", flush=True)
+        res["sp_add_norm"].setdefault("enabled", ctx.sp_ok)
+        return res
+
     def _gate_overlap_by_time(self, layer, x, rec: dict) -> None:
         """Measured, not guessed: the pipeline stays on only where it beats the plain GEMM → all-reduce sequence on THIS
         system (two chunk counts tried; TP rank 0's clock decides for the group).  With every rank on its own GPU the

@@ -56,6 +56,31 @@ def test_gemm_all_reduce_overlap_runs_and_equals_the_plain_path():
     assert piped["tuning_source"] == "probe"                # one launch-shape sweep per start-up: the probe child's
 
 
+@pytest.mark.parametrize("model,tp,ep,a2a", [("tiny-llama-tp", 2, 1, 0), ("tiny-llama-tp8", 8, 1, 0), ("tiny-mixtral-tp", 2, 2, 0),
+                                             ("tiny-mixtral-tp8", 8, 8, 64)])
+def test_sequence_parallel_add_norm_equals_the_plain_norms(model, tp, ep, a2a, tmp_path):
+    """Sequence-parallel steps: the row-parallel GEMMs (and the MoE block) leave their partial sums in the IPC staging
+    buffer and ONE kernel reduces them, adds the residual and applies the RMSNorm on this rank's T / tp rows, then
+    gathers (`all_reduce_add_norm_kernel`; after the expert-parallel dispatch: slice norm + all-gather).  Against the
+    same ranks with the plain all-reduce → whole-batch norm: start-up self-test, first-step logits, greedy tokens."""
+    rng = np.random.default_rng(8)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (700, 333, 41)]     # 1074 rows: not a multiple of 8
+    logits, outs = {}, {}
+    common = {"DLI_OVERLAP_MIN_ROWS": "1000000", "DLI_TEST_EP_A2A": str(a2a)}
+    for name, env in (("sp", {"DLI_SP_FORCE": "1", "DLI_SP_MIN_BYTES": "65536"}), ("plain", {"DLI_SP_NORM": "0"})):
+        f = str(tmp_path / f"logits_{name}.pt")
+        outs[name] = run(model, tp, ep, prompts, dict(common, DLI_DUMP_LOGITS=f, **env))
+        logits[name] = torch.load(f, weights_only=True)
+    st = outs["sp"]["selftest"]["sp_add_norm"]
+    assert st["ok"] is True and st["enabled"] is True and "skipped" not in st, st
+    assert outs["sp"]["sp_norm_calls"] > 0 and outs["plain"]["sp_norm_calls"] == 0
+    assert outs["sp"]["mixed_graph_steps"] > 0
+    cos = torch.nn.functional.cosine_similarity(logits["sp"], logits["plain"], dim=0).item()
+    assert cos > 0.9995, cos
+    agree = np.mean([np.mean(np.array(a) == np.array(b)) for a, b in zip(outs["sp"]["greedy"], outs["plain"]["greedy"])])
+    assert agree >= 0.9, (outs["sp"]["greedy"], outs["plain"]["greedy"])
+
+
 @pytest.mark.parametrize("model,ep", [("tiny-llama-tp8", 1), ("tiny-mixtral-tp8", 8)])
 def test_tp8_matches_tp1_on_gpu(model, ep):
     """The degree BASELINE configs 4 and 5 run at: 8 ranks (sharing the device on a one-GPU box), the 8-peer custom

@@ -36,6 +36,7 @@ def main():
             "custom_ar": bool(ctx is not None and ctx.custom_ar is not None),
             "overlap_calls": RowParallelLinear.overlap_calls - warm_calls, "overlap_calls_at_warmup": warm_calls, "selftest": eng.runner.selftest,
             "a2a_calls": ctx.comm["a2a_calls"] if ctx is not None else 0,
+            "sp_norm_calls": ctx.comm["sp_norm_calls"] if ctx is not None else 0,
             "device_backend": job_info().get("device_backend"), "tuning_source": (job_info().get("tp_group_tuning") or {}).get("source")}
     eng.shutdown()
     join_children()
