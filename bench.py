@@ -95,6 +95,8 @@ def parse(argv=None):
     ap.add_argument("--no-gemm-tune", action="store_true", help="skip the start-up GEMM dispatch measurement (A/B)")
     ap.add_argument("--no-mixed-graphs", action="store_true", help="capture pure-decode steps only (A/B of the mixed-step graphs)")
     ap.add_argument("--no-custom-ar", action="store_true")
+    ap.add_argument("--no-ttft-tpot-trade", action="store_true",
+                    help="TPOT control as a fixed per-step cap (A/B of SchedulerConfig.ttft_tpot_trade)")
     ap.add_argument("--fcfs", action="store_true", help="plain FCFS admission (default: requests past their TTFT deadline yield)")
     ap.add_argument("--sync-steps", action="store_true", help="disable pipelined stepping (one step in flight at a time)")
     ap.add_argument("--seed", type=int, default=0)
@@ -303,6 +305,7 @@ def main():
                                              max_model_len=2112, long_prefill_chunk=args.chunk,
                                              ttft_slo=None if args.fcfs else slo[0],
                                              tpot_slo=slo[1] if args.tpot_control else None,
+                                             ttft_tpot_trade=not args.no_ttft_tpot_trade,
                                              max_queue_delay=None if args.fcfs else qdelay),
                        parallel=ParallelConfig(tp=tp_eff, ep=args.ep if args.emulate_tp <= 1 else (tp_eff if args.ep > 1 else 1),
                                                custom_all_reduce=not args.no_custom_ar,
@@ -501,6 +504,7 @@ def run_fixed(args, eng, mcfg, layout, slo, slo_rows, qps, sync_drivers, on_gpu,
         "eager_steps": eng.runner.stats["eager_steps"] - before[5]["eager_steps"],
         "ar_fallbacks": eng.runner.stats["ar_fallbacks"],
         "running": m.running, "waiting": m.waiting, "kv_used": m.kv_used_frac, "preemptions": m.preemptions,
+        "burst_steps": eng.scheduler.num_burst_steps, "burst_seconds": round(eng.scheduler.burst_seconds, 3),
         "backlog_s": float(time.perf_counter() - t0 - (stamps[rp.nxt - 1] if rp.nxt else 0.0)),
         "arrived": rp.nxt - n_inj_before, "late_queue": len(eng.scheduler.late), "comm": comm_delta,
         "sustained": sus, "replay_seconds": t_end - t0, "steady": steady, "ramp_seconds": t_steady - t0,
@@ -615,6 +619,7 @@ def run_sweep(args, eng, mcfg, layout, slo_rows, qps, sync_drivers):
         sc.tpot_slo = slo[1] if (args.tpot_control or row_name == "interactive") else None
         eng.scheduler.dyn_budget = sc.max_num_batched_tokens
         eng.scheduler.step_ema = None
+        eng.scheduler.credit = eng.scheduler.granted_inflight = 0.0
         out = []
         for pi, q in enumerate(pts):
             ramp, win, tail = args.sweep_ramp, args.sweep_window, 12.0

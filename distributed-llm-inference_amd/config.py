@@ -154,6 +154,12 @@ class SchedulerConfig:
     tpot_slo: Optional[float] = None
     tpot_slo_margin: float = 0.85           # aim the step time at this fraction of tpot_slo
     min_prefill_tokens: int = 128           # the prefill share never shrinks below this while decodes meet the target
+    # TTFT ⇄ TPOT trade (both SLOs set): TPOT is a per-request MEAN, so step time saved under ``tpot_slo`` by earlier steps
+    # is credit; it is spent on a longer step when waiting prompts are about to miss their TTFT deadline (a burst drains
+    # in fewer steps instead of queueing behind a fixed per-step cap), and repaid by the margin of the steps that follow.
+    ttft_tpot_trade: bool = True
+    burst_credit_cap: float = 6.0           # most credit held / spent on one step, in units of tpot_slo
+    burst_urgent_frac: float = 0.3          # a waiting prompt is urgent once this fraction of ttft_slo has passed
 
 
 @dataclass

@@ -208,7 +208,7 @@ class LLMEngine:
         # time between two consecutive results IS the step time; otherwise launch → result
         dt = t2 - max(t_launch, self._last_result_time) if self._last_result_time else t2 - t_launch
         self._last_result_time = t2
-        self.scheduler.observe_step(dt, batch.total_tokens)
+        self.scheduler.observe_step(dt, batch.total_tokens, batch.burst_grant)
         return outs
 
     def _recover_from_comm_fault(self, batch) -> list[RequestOutput]:

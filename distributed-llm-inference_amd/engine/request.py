@@ -101,6 +101,7 @@ class ScheduledBatch:
     total_tokens: int
     sample_mask: np.ndarray                # bool [B]: sequence produces a token this step
     preempted: list = field(default_factory=list)
+    burst_grant: float = 0.0               # seconds of step time above the TPOT target granted to urgent prompts
 
 
 @dataclass

@@ -22,6 +22,9 @@ Policy, one call per engine step:
    ``tpot_slo`` — the engine feeds measured step times back (``observe_step``) and the prefill share
    of the token budget follows them, so that a burst of prompts cannot stretch the inter-token time of
    the running decodes past the target; when even the decode-only step is too slow, admission pauses.
+   With both set, the two are traded (``ttft_tpot_trade``): TPOT is a per-request mean, so the time that steps stay
+   under ``tpot_slo`` accumulates as credit, and a step may run longer — a grant paid from that credit — when
+   waiting prompts would otherwise miss their TTFT deadline.
 
 KV accounting lives in the C++ ``BlockManager`` (``csrc/runtime/block_manager.cpp``).
 """
@@ -57,6 +60,11 @@ class Scheduler:
         # TPOT controller state
         self.dyn_budget = cfg.max_num_batched_tokens        # current total-token target of a step
         self.step_ema: Optional[float] = None
+        self.credit = 0.0                                  # seconds of step time saved under tpot_slo (TTFT ⇄ TPOT trade)
+        self.granted_inflight = 0.0                        # grants of launched steps whose time has not been observed yet
+        self.tok_rate: Optional[float] = None              # tokens per second of recent steps
+        self.num_burst_steps = 0
+        self.burst_seconds = 0.0
 
     # ------------------------------------------------------------------ queue management
     def add(self, req: Request) -> None:
@@ -143,14 +151,22 @@ class Scheduler:
         return len(victims)
 
     # ------------------------------------------------------------------ TPOT control
-    def observe_step(self, seconds: float, tokens: int) -> None:
-        """Feedback from the engine: wall time of a finished step and the tokens it computed.  Multiplicative
-        control of the step's token target towards ``tpot_slo · tpot_slo_margin`` seconds per step."""
+    def observe_step(self, seconds: float, tokens: int, grant: float = 0.0) -> None:
+        """Feedback from the engine: wall time of a finished step, the tokens it computed and the burst grant it was
+        scheduled with.  Multiplicative control of the step's token target towards ``tpot_slo · tpot_slo_margin``
+        (+ the grant) seconds per step; the distance to ``tpot_slo`` itself goes to the credit account."""
         cfg = self.cfg
         if cfg.tpot_slo is None or seconds <= 0:
             return
-        self.step_ema = seconds if self.step_ema is None else 0.6 * self.step_ema + 0.4 * seconds
-        target = cfg.tpot_slo * cfg.tpot_slo_margin
+        if tokens > 0:
+            rate = tokens / seconds
+            self.tok_rate = rate if self.tok_rate is None else 0.7 * self.tok_rate + 0.3 * rate
+        cap = cfg.burst_credit_cap * cfg.tpot_slo
+        self.credit = min(max(self.credit + 0.95 * cfg.tpot_slo - seconds, -cap), cap)
+        self.granted_inflight = max(self.granted_inflight - grant, 0.0)
+        if grant <= 0:                                     # a deliberate long step says nothing about the usual ones
+            self.step_ema = seconds if self.step_ema is None else 0.6 * self.step_ema + 0.4 * seconds
+        target = cfg.tpot_slo * cfg.tpot_slo_margin + grant
         ratio = target / seconds
         if ratio < 1.0:                                    # too slow: shrink relative to what the step really held
             basis = min(self.dyn_budget, max(tokens, 1))
@@ -158,6 +174,33 @@ class Scheduler:
         else:                                              # head-room: grow gently (a burst arrives faster than it leaves)
             new = self.dyn_budget * min(ratio, 1.1)
         self.dyn_budget = int(min(max(new, cfg.min_prefill_tokens), cfg.max_num_batched_tokens))
+
+    def _burst_grant(self, now: float, prefill_left: int) -> float:
+        """Seconds by which this step may exceed the TPOT target: as much as the urgent prompts (waiting, or admitted
+        but still without their first token, for longer than ``burst_urgent_frac · ttft_slo``) need beyond the step's
+        prefill share, bounded by the credit not yet promised to steps in flight."""
+        cfg = self.cfg
+        if not (cfg.ttft_tpot_trade and cfg.ttft_slo is not None and self.tok_rate):
+            return 0.0
+        avail = self.credit - self.granted_inflight
+        if avail <= 0:
+            return 0.0
+        cutoff = now - cfg.burst_urgent_frac * cfg.ttft_slo
+        need = 0
+        for q in (self.waiting, self.running):
+            seen = 0
+            for r in (q if q is self.waiting else reversed(q)):      # running: the most recently admitted sit at the tail
+                seen += 1
+                if seen > 64:
+                    break
+                if r.num_output == 0 and r.preemptions == 0 and r.arrival < cutoff:
+                    need += r.num_tokens - r.num_computed
+                elif q is self.waiting:
+                    break                                             # arrival order: the rest is younger
+        extra = need - prefill_left
+        if extra <= 0:
+            return 0.0
+        return min(extra / self.tok_rate, avail)
 
     def _shed_overdue(self, now: float) -> None:
         lim = self.cfg.max_queue_delay
@@ -181,6 +224,7 @@ class Scheduler:
         budget = cfg.max_num_batched_tokens
         picked: list[tuple[Request, int]] = []
         preempted: list[Request] = []
+        grant = 0.0
         now = time.perf_counter()
         self._shed_overdue(now)
         # prefill share of this step: everything (no TPOT target), or what the controller leaves after the decodes
@@ -193,6 +237,9 @@ class Scheduler:
                 admit = False                              # the decode population alone is over the target
             elif prefill_left < cfg.min_prefill_tokens:
                 prefill_left = cfg.min_prefill_tokens       # keep prompts trickling in while decodes meet the target
+            grant = self._burst_grant(now, prefill_left) if admit else 0.0
+            if grant > 0:
+                prefill_left += int(grant * self.tok_rate)
 
         # 1) running sequences
         i = 0
@@ -281,7 +328,15 @@ class Scheduler:
         num_new = np.fromiter((p[1] for p in picked), dtype=np.int32, count=len(picked))
         num_decode = int((num_new == 1).sum())
         sample_mask = np.fromiter((r.num_computed + n == r.num_tokens for r, n in picked), dtype=bool, count=len(picked))
-        return ScheduledBatch(reqs, num_new, num_decode, int(num_new.sum()), sample_mask, preempted)
+        total = int(num_new.sum())
+        if grant > 0:                                       # charge what the step really took of the grant
+            used = max(total - (self.dyn_budget if cfg.tpot_slo is not None else total), 0) / self.tok_rate
+            grant = min(grant, used)
+            if grant > 0:
+                self.granted_inflight += grant
+                self.num_burst_steps += 1
+                self.burst_seconds += grant
+        return ScheduledBatch(reqs, num_new, num_decode, total, sample_mask, preempted, grant)
 
     # ------------------------------------------------------------------ around the forward pass
     # A step is accounted for in two halves so that step N+1 can be scheduled and queued on the GPU

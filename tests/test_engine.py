@@ -297,6 +297,53 @@ def test_slo_aware_admission_serves_requests_that_can_still_make_their_deadline_
     assert order2 == ["late", "fresh"]
 
 
+def test_ttft_tpot_trade_spends_saved_step_time_on_urgent_prompts_only():
+    """with both SLOs set, the time that steps stay under `tpot_slo` is credit (TPOT is a
+    per-request mean) and an urgent prompt — waiting for more than `burst_urgent_frac · ttft_slo` — gets a longer step
+    paid from it; a fresh prompt does not, and without credit nobody does."""
+    import time
+    p = SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True)
+
+    def engine_with(credit_steps):
+        eng = make_engine(max_seqs=8, max_tokens=4096, num_blocks=512)
+        sc = eng.cfg.sched
+        sc.ttft_slo, sc.tpot_slo, sc.max_num_batched_tokens, sc.long_prefill_chunk, sc.token_alignment = 10.0, 0.030, 4096, 4096, 0
+        sc.max_model_len = 2048
+        s = eng.scheduler
+        for _ in range(credit_steps):                        # steps of 20 ms at 256 tokens: 8.5 ms under 0.95 · tpot_slo each
+            s.observe_step(0.020, 256)
+        s.dyn_budget = 256                                   # what the controller would have settled at
+        return eng, s
+
+    eng, s = engine_with(10)
+    assert abs(s.credit - 10 * (0.95 * 0.030 - 0.020)) < 1e-9 and abs(s.tok_rate - 12800) < 1
+    now = time.perf_counter()
+    eng.add_request("urgent", prompt_ids=list(range(3, 1503)), params=p, arrival=now - 4.0)       # 40 % of its TTFT gone
+    b = s.schedule()
+    want = 256 + int(min(s.credit, (1500 - 256) / s.tok_rate) * s.tok_rate)
+    assert b.burst_grant > 0 and abs(b.total_tokens - want) <= 1 and b.total_tokens > 256, (b.total_tokens, want)
+    assert abs(s.granted_inflight - b.burst_grant) < 1e-12 and s.num_burst_steps == 1
+    # credit promised to the step in flight is not promised twice
+    eng.add_request("urgent2", prompt_ids=list(range(3, 1503)), params=p, arrival=now - 4.0)
+    b2 = s.schedule()
+    assert b2.burst_grant <= s.credit - b.burst_grant + 1e-9
+    # the long step is judged against its own target (no collapse of the token target), and it costs credit
+    before, budget = s.credit, s.dyn_budget
+    s.observe_step(0.030 * 0.85 + b.burst_grant, b.total_tokens, b.burst_grant)
+    assert s.dyn_budget >= budget and s.credit < before and abs(s.granted_inflight - b2.burst_grant) < 1e-12
+
+    eng, s = engine_with(10)                                 # a fresh prompt: the usual prefill share
+    eng.add_request("fresh", prompt_ids=list(range(3, 1503)), params=p, arrival=time.perf_counter())
+    b = s.schedule()
+    assert b.burst_grant == 0 and b.total_tokens == 256
+
+    eng, s = engine_with(0)                                  # urgent but no credit
+    s.tok_rate = 12800.0
+    eng.add_request("urgent", prompt_ids=list(range(3, 1503)), params=p, arrival=time.perf_counter() - 4.0)
+    b = s.schedule()
+    assert b.burst_grant == 0 and b.total_tokens == 256
+
+
 def test_decode_sized_gemm_dispatch_rule():
     """ops.linear: which (rows, N, K) go to the weight-streaming kernel (csrc/kernels/skinny_gemm.hip)."""
     from dli_amd import ops
