@@ -338,8 +338,13 @@ def bench_midm(quick):
                         if ksp <= K // 256:
                             sk[ksp] = round(timeit_graph(call(lambda a, w: lib.dense_gemm256(a, w, swiglu, ksp)), 2 * copies) * 1e6, 1)
                 best_sk = min(sk, key=sk.get) if sk else None
+                from dli_amd.ops.gemm_plan import GemmPlan
+                tail = None
+                if sk and GemmPlan.tail_slices(M, N, K, swiglu):     # whole rounds plain, remainder tiles K-split
+                    tail = {"slices": GemmPlan.tail_slices(M, N, K, swiglu),
+                            "us": round(timeit_graph(call(lambda a, w: lib.dense_gemm256(a, w, swiglu, 1, None, True)), 2 * copies) * 1e6, 1)}
                 report(f"midm({model}_{name})", t_ops, flops=fl, M=M, N=N, K=K, library_gemm_us=round(t_lib * 1e6, 1),
-                       tile256_splitk_us=sk, best_splitk=best_sk,
+                       tile256_splitk_us=sk, best_splitk=best_sk, tile256_tail=tail,
                        best_splitk_vs_library_path=round(t_lib_path * 1e6 / sk[best_sk], 3) if sk else None,
                        library_path_us=round(t_lib_path * 1e6, 1), roofline_us=round(roof * 1e6, 1),
                        library_off_roofline=round(t_lib / roof, 2), dispatched_off_roofline=round(t_ops / roof, 2),

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
     const uint16_t* __restrict__ A, int64_t a_stride, const uint16_t* __restrict__ W, int64_t w_expert_stride,
     const int* __restrict__ sorted_ids, const int* __restrict__ tile_expert, const int* __restrict__ meta,
     const float* __restrict__ topk_w, int top_k, void* __restrict__ out_, int64_t out_stride, int M, int K, int N_half,
-    int n_col_blocks, int k_splits, int64_t slab_elems) {
+    int n_col_blocks, int k_splits, int64_t slab_elems, int lin_begin, int lin_count) {
   uint16_t* out = reinterpret_cast<uint16_t*>(out_);
   __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE_BYTES];
 
@@ -69,20 +69,31 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   // and XCD x runs the x-th eighth of that order: the ≈ 32 blocks resident on an XCD at a time are 4 row tiles × 8
   // column blocks — each operand K-slice is fetched into that L2 once and used 4–8 times — and the eighths differ by
   // at most one tile (whole super-tiles per XCD left XCDs 4–7 idle for the last 1/8 of a 28-super-tile launch).
+  // RANGE mode (dense only, lin_count > 0): this launch covers the tiles lin_begin … lin_begin + lin_count − 1 of the
+  // un-split tile order, each cut into k_splits K-slices (slowest index).  launch_dense_gemm256 uses it to run the whole
+  // rounds of a GEMM (a multiple of the CU count, one 512-thread workgroup per CU) as plain tiles and the REMAINDER
+  // tiles K-split over the otherwise idle CUs: 784 tiles are 3 rounds + 16 tiles × 8 slices, not 4 rounds.
+  const bool ranged = !GROUPED && lin_count > 0;
   const int n_tiles = GROUPED ? meta[0] : (M + TM - 1) / TM;
-  const int n_virtual = n_col_blocks * k_splits;             // split-K slices are extra "columns" (slowest index)
-  const int total = n_tiles * n_virtual;
+  const int n_virtual = ranged ? n_col_blocks : n_col_blocks * k_splits;   // split-K slices are extra "columns" (slowest index)
+  const int total = ranged ? lin_count * k_splits : n_tiles * n_virtual;
   const int per_xcd = (total + 7) >> 3;
   const int in_xcd = blockIdx.x >> 3;
-  const int lin = (blockIdx.x & 7) * per_xcd + in_xcd;
-  if (in_xcd >= per_xcd || lin >= total) return;
+  const int j_lin = (blockIdx.x & 7) * per_xcd + in_xcd;
+  if (in_xcd >= per_xcd || j_lin >= total) return;
+  int split = 0, lin = j_lin, lin_local = 0;
+  if (ranged) {
+    split = j_lin / lin_count;
+    lin_local = j_lin - split * lin_count;
+    lin = lin_begin + lin_local;
+  }
   constexpr int GW = 8;
   const int grp = lin / (GW * n_tiles), within = lin - grp * (GW * n_tiles);
   const int gw = min(GW, n_virtual - grp * GW);              // the last group may be narrower
   const int tile = within / gw;
   const int col_virtual = grp * GW + (within - tile * gw);
-  const int split = col_virtual / n_col_blocks;
-  const int col_block = col_virtual - split * n_col_blocks;
+  if (!ranged) split = col_virtual / n_col_blocks;
+  const int col_block = ranged ? col_virtual : col_virtual - split * n_col_blocks;
   const int e = GROUPED ? tile_expert[tile] : 0;
   const uint16_t* We = W + (int64_t)e * w_expert_stride;
   const int n0 = col_block * (is_swiglu(EPI) ? TN / 2 : TN);
@@ -250,23 +261,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
 #undef G256_STEP
 
   // ---- epilogue.  acc[m][n][r]: row = wr·128 + m·16 + col, output column = wc·64 + n·16 + 4g + r
+  // dense split-K slabs: whole-matrix slabs [split][M][ldc], or — RANGE mode — compact per-tile slabs
+  // [split][tile of the range][256 rows][256 floats] (SwiGLU: gate columns 0…127, up columns 128…255)
+  float* slab = reinterpret_cast<float*>(out_);
+  int64_t slab_ld = out_stride;
+  int slab_col0 = n0, slab_half = N_half;
+  if (ranged && (EPI == EPI_PLAIN_SPLITK || EPI == EPI_SWIGLU_SPLITK)) {
+    slab += ((int64_t)split * lin_count + lin_local) * (TM * TN);
+    slab_ld = TN;
+    slab_col0 = 0;
+    slab_half = TN / 2;
+  } else {
+    slab += split * slab_elems;
+  }
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const int prow = tile * TM + wr * 128 + m * 16 + col;
+    const int lrow = wr * 128 + m * 16 + col;
+    const int prow = tile * TM + lrow;
     const int sid = GROUPED ? sorted_ids[prow] : (prow < M ? prow : -1);
+    const int64_t srow = (ranged && (EPI == EPI_PLAIN_SPLITK || EPI == EPI_SWIGLU_SPLITK)) ? lrow : prow;
     if (EPI == EPI_PLAIN_SPLITK) {
       if (sid >= 0) {
-        float* dst = reinterpret_cast<float*>(out_) + split * slab_elems + (int64_t)prow * out_stride + n0 + wc * 64 + 4 * g;
+        float* dst = slab + srow * slab_ld + slab_col0 + wc * 64 + 4 * g;
 #pragma unroll
         for (int n = 0; n < 4; ++n) *reinterpret_cast<f32x4*>(dst + n * 16) = acc[m][n];
       }
     } else if (EPI == EPI_SWIGLU_SPLITK) {
       if (sid >= 0) {                                            // raw partials: gate at column c, up at N_half + c of the slab row
-        float* dst = reinterpret_cast<float*>(out_) + split * slab_elems + (int64_t)prow * out_stride + n0 + wc * 32 + 4 * g;
+        float* dst = slab + srow * slab_ld + slab_col0 + wc * 32 + 4 * g;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           *reinterpret_cast<f32x4*>(dst + n * 16) = acc[m][n];
-          *reinterpret_cast<f32x4*>(dst + N_half + n * 16) = acc[m][n + 2];
+          *reinterpret_cast<f32x4*>(dst + slab_half + n * 16) = acc[m][n + 2];
         }
       }
     } else if (EPI == EPI_SWIGLU) {
@@ -326,7 +352,7 @@ void launch_grouped_gemm256(int epilogue, const void* A, int64_t a_stride, const
 #define G256_GO(EPI)                                                                                                       \
   hipLaunchKernelGGL((gemm256_kernel<EPI, true>), grid, dim3(512), 0, stream, (const uint16_t*)A, a_stride, (const uint16_t*)W, \
                      w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, out_stride, 0, K, N_out, n_col_blocks, \
-                     k_splits, slab_elems)
+                     k_splits, slab_elems, 0, 0)
   if (epilogue == EPI_SWIGLU) G256_GO(EPI_SWIGLU);
   else if (epilogue == EPI_SCATTER) G256_GO(EPI_SCATTER);
   else G256_GO(EPI_SCATTER_SPLITK);
@@ -358,28 +384,81 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// out tile (tile, col_block) of the range = Σ_s compact slab_s, epilogue applied: the reduce pass of the RANGE-mode tail
+// (one workgroup per quarter tile: 64 rows)
+template <bool SWIGLU>
+__global__ __launch_bounds__(256) void splitk_reduce_tiles_kernel(const float* __restrict__ slabs, int n_slabs, int lin_begin,
+                                                                  int lin_count, int n_tiles, int n_col_blocks, int M,
+                                                                  uint16_t* __restrict__ out, int64_t out_stride) {
+  using namespace g256;
+  const int lin_local = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  const int lin = lin_begin + lin_local;
+  constexpr int GW = 8;
+  const int grp = lin / (GW * n_tiles), within = lin - grp * (GW * n_tiles);
+  const int gw = min(GW, n_col_blocks - grp * GW);
+  const int tile = within / gw;
+  const int col_block = grp * GW + (within - tile * gw);
+  constexpr int VEC_PER_ROW = (SWIGLU ? TN / 2 : TN) / 4;      // output vectors of 4 columns per tile row
+  constexpr int ROWS_PER_PASS = 256 / VEC_PER_ROW;
+  const int v = threadIdx.x % VEC_PER_ROW, r_in = threadIdx.x / VEC_PER_ROW;
+  const float* base = slabs + (int64_t)lin_local * (TM * TN);
+  const int64_t slab_stride = (int64_t)lin_count * (TM * TN);
+  const int n0 = col_block * (SWIGLU ? TN / 2 : TN);
+  for (int r = quarter * 64 + r_in; r < quarter * 64 + 64; r += ROWS_PER_PASS) {
+    const int row = tile * TM + r;
+    if (row >= M) break;
+    const float* p = base + r * TN + v * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_slabs; ++s) {
+      a += *reinterpret_cast<const f32x4*>(p + s * slab_stride);
+      if (SWIGLU) b += *reinterpret_cast<const f32x4*>(p + s * slab_stride + TN / 2);
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float val = SWIGLU ? a[q] * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * a[q])) * b[q] : a[q];
+      o[q] = (short)f2bf(val);
+    }
+    *reinterpret_cast<bf16x4*>(out + (int64_t)row * out_stride + n0 + v * 4) = o;
+  }
+}
+
+// How launch_dense_gemm256 would cut the REMAINDER tiles of a GEMM (tiles beyond the last whole round of one tile per
+// CU): {remainder tiles, K-slices}; slices == 0: no cut (no remainder, no whole round before it, or more than half a
+// round of remainder — then slices would only add a reduce pass).
+void dense_gemm256_tail_plan(int M, int K, int N_out, bool swiglu, int* tail_tiles, int* tail_slices) {
+  using namespace g256;
+  constexpr int NUM_CU = 256;
+  const int n_lin = ((M + TM - 1) / TM) * (N_out / (swiglu ? TN / 2 : TN));
+  const int r = n_lin % NUM_CU;
+  int s = 0;
+  if (r > 0 && n_lin > NUM_CU && r <= NUM_CU / 2) s = std::min({8, NUM_CU / r, K / TK / 4});
+  *tail_tiles = r;
+  *tail_slices = s >= 2 ? s : 0;
+}
+
 // Dense y = x · Wᵀ (swiglu = false: W [N, K] → y [M, N]) or y = silu(x · W_gateᵀ) ⊙ (x · W_upᵀ)
 // (swiglu = true: W = [W_gate; W_up] of 2·N_out rows → y [M, N_out]).  K % 64 == 0, N_out % 256 (128 with swiglu) == 0.
 // k_splits > 1: K is cut into that many slices (each at least one K-step), partial sums go through `workspace`
 // (fp32, k_splits · M · (swiglu ? 2 : 1) · N_out elements) and a reduce pass — the mid-M path: with one or two row tiles
 // the column blocks alone leave most of the 256 CUs without a tile, and the GEMM is a weight stream that needs them all.
+// split_tail (k_splits == 1): whole rounds as plain tiles, the remainder tiles K-split per dense_gemm256_tail_plan
+// (`workspace`: tail slices · tail tiles · 65536 floats).
 void launch_dense_gemm256(bool swiglu, const void* x, int64_t x_stride, const void* W, void* out, int64_t out_stride, int M,
-                          int K, int N_out, int k_splits, float* workspace, hipStream_t stream) {
+                          int K, int N_out, int k_splits, float* workspace, bool split_tail, hipStream_t stream) {
   using namespace g256;
   if (M == 0) return;
   const int n_tiles = (M + TM - 1) / TM;
   const int n_col_blocks = N_out / (swiglu ? TN / 2 : TN);
+#define G256_DENSE(EPI, grid_, out_ptr_, ld_, splits_, slab_, begin_, count_)                                                    \
+  hipLaunchKernelGGL((gemm256_kernel<EPI, false>), dim3(grid_), dim3(512), 0, stream, (const uint16_t*)x, x_stride,              \
+                     (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, out_ptr_, ld_, M, K, N_out,          \
+                     n_col_blocks, splits_, slab_, begin_, count_)
   if (k_splits > 1) {
     const int64_t ldc = (int64_t)N_out * (swiglu ? 2 : 1), slab = (int64_t)M * ldc;
-    dim3 grid((n_tiles * n_col_blocks * k_splits + 7) / 8 * 8);
-    if (swiglu)
-      hipLaunchKernelGGL((gemm256_kernel<EPI_SWIGLU_SPLITK, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
-                         (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, workspace, ldc, M, K, N_out,
-                         n_col_blocks, k_splits, slab);
-    else
-      hipLaunchKernelGGL((gemm256_kernel<EPI_PLAIN_SPLITK, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
-                         (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, workspace, ldc, M, K, N_out,
-                         n_col_blocks, k_splits, slab);
+    const int grid = (n_tiles * n_col_blocks * k_splits + 7) / 8 * 8;
+    if (swiglu) G256_DENSE(EPI_SWIGLU_SPLITK, grid, workspace, ldc, k_splits, slab, 0, 0);
+    else G256_DENSE(EPI_PLAIN_SPLITK, grid, workspace, ldc, k_splits, slab, 0, 0);
     const int blocks = (int)std::min<int64_t>(((int64_t)M * (N_out / 4) + 255) / 256, 2048);
     if (swiglu)
       hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, stream, workspace, k_splits, slab, ldc, M, N_out,
@@ -389,15 +468,28 @@ void launch_dense_gemm256(bool swiglu, const void* x, int64_t x_stride, const vo
                          (uint16_t*)out, out_stride);
     return;
   }
-  dim3 grid((n_tiles * n_col_blocks + 7) / 8 * 8);
-  if (swiglu)
-    hipLaunchKernelGGL((gemm256_kernel<EPI_SWIGLU, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
-                       (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, out, out_stride, M, K, N_out,
-                       n_col_blocks, 1, (int64_t)0);
-  else
-    hipLaunchKernelGGL((gemm256_kernel<EPI_PLAIN, false>), grid, dim3(512), 0, stream, (const uint16_t*)x, x_stride,
-                       (const uint16_t*)W, (int64_t)0, nullptr, nullptr, nullptr, nullptr, 1, out, out_stride, M, K, N_out,
-                       n_col_blocks, 1, (int64_t)0);
+  int r = 0, s = 0;
+  if (split_tail) dense_gemm256_tail_plan(M, K, N_out, swiglu, &r, &s);
+  if (s >= 2) {
+    const int n_full = n_tiles * n_col_blocks - r;
+    const int grid_a = (n_full + 7) / 8 * 8, grid_b = (r * s + 7) / 8 * 8;
+    if (swiglu) {
+      G256_DENSE(EPI_SWIGLU, grid_a, out, out_stride, 1, (int64_t)0, 0, n_full);
+      G256_DENSE(EPI_SWIGLU_SPLITK, grid_b, workspace, (int64_t)TN, s, (int64_t)0, n_full, r);
+      hipLaunchKernelGGL(splitk_reduce_tiles_kernel<true>, dim3(r * 4), dim3(256), 0, stream, workspace, s, n_full, r, n_tiles,
+                         n_col_blocks, M, (uint16_t*)out, out_stride);
+    } else {
+      G256_DENSE(EPI_PLAIN, grid_a, out, out_stride, 1, (int64_t)0, 0, n_full);
+      G256_DENSE(EPI_PLAIN_SPLITK, grid_b, workspace, (int64_t)TN, s, (int64_t)0, n_full, r);
+      hipLaunchKernelGGL(splitk_reduce_tiles_kernel<false>, dim3(r * 4), dim3(256), 0, stream, workspace, s, n_full, r, n_tiles,
+                         n_col_blocks, M, (uint16_t*)out, out_stride);
+    }
+    return;
+  }
+  const int grid = (n_tiles * n_col_blocks + 7) / 8 * 8;
+  if (swiglu) G256_DENSE(EPI_SWIGLU, grid, out, out_stride, 1, (int64_t)0, 0, 0);
+  else G256_DENSE(EPI_PLAIN, grid, out, out_stride, 1, (int64_t)0, 0, 0);
+#undef G256_DENSE
 }
 
 }  // namespace dli

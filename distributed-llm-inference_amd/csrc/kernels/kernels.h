@@ -56,7 +56,8 @@ void launch_grouped_gemm256(int epilogue, const void* A, int64_t a_stride, const
                             void* out, int64_t out_stride, int K, int N_out, int max_tiles, int k_splits, int64_t slab_elems,
                             hipStream_t stream);
 void launch_dense_gemm256(bool swiglu, const void* x, int64_t x_stride, const void* W, void* out, int64_t out_stride, int M,
-                          int K, int N_out, int k_splits, float* workspace, hipStream_t stream);
+                          int K, int N_out, int k_splits, float* workspace, bool split_tail, hipStream_t stream);
+void dense_gemm256_tail_plan(int M, int K, int N_out, bool swiglu, int* tail_tiles, int* tail_slices);
 void launch_moe_sum(const void* y, bool y_fp32, int n_slabs, int64_t slab_elems, const int* ids, int expert_offset, int E_local,
                     int top_k, int T, int H, void* out, hipStream_t stream);
 

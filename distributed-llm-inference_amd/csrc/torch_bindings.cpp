@@ -256,7 +256,9 @@ void gather_sampled(Tensor input, const Tensor& src, const Tensor& sampled) {
 }
 
 // y = x · Wᵀ on the 256×256×64 tile kernel (gemm256.hip); swiglu: W = [gate; up] rows, y = silu(x·gateᵀ) ⊙ (x·upᵀ)
-Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_splits, const c10::optional<Tensor>& out_) {
+// split_tail (k_splits == 1): the tiles beyond the last whole round of one tile per CU are K-split over the idle CUs
+Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_splits, const c10::optional<Tensor>& out_,
+                     bool split_tail) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
@@ -268,8 +270,15 @@ Tensor dense_gemm256(const Tensor& x, const Tensor& w, bool swiglu, int64_t k_sp
   Tensor out = take_out(out_, M, n_out, x);
   Tensor ws;                                                  // fp32 partial slabs of the split-K path
   if (k_splits > 1) ws = at::empty({k_splits, M, N}, x.options().dtype(at::kFloat));
-  dli::launch_dense_gemm256(swiglu, x.data_ptr(), x.stride(0), w.data_ptr(), out.data_ptr(), n_out, (int)M, (int)K, (int)n_out,
-                            (int)k_splits, k_splits > 1 ? ws.data_ptr<float>() : nullptr, cur_stream(x));
+  split_tail = split_tail && k_splits == 1;
+  if (split_tail) {
+    int r = 0, s = 0;
+    dli::dense_gemm256_tail_plan((int)M, (int)K, (int)n_out, swiglu, &r, &s);
+    if (s >= 2) ws = at::empty({(int64_t)s * r, 256 * 256}, x.options().dtype(at::kFloat));
+    else split_tail = false;
+  }
+  dli::launch_dense_gemm256(swiglu, x.data_ptr(), x.stride(0), w.data_ptr(), out.data_ptr(), out.stride(0), (int)M, (int)K, (int)n_out,
+                            (int)k_splits, ws.defined() ? ws.data_ptr<float>() : nullptr, split_tail, cur_stream(x));
   return out;
 }
 
@@ -551,7 +560,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None) -> Tensor", &skinny_linear);
-  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None) -> Tensor", &dense_gemm256);
+  m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None, bool split_tail=False) -> Tensor", &dense_gemm256);
   m.def("ar_staging_tensor(int state, int rows, int cols, Tensor like) -> Tensor", &ar_staging_tensor);
   m.def("ar_all_reduce_add_norm(int state, Tensor staged, Tensor(a!) residual, Tensor weight, float eps, Tensor(b!) out, int blocks=0) -> ()",
         &ar_all_reduce_add_norm);

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import reference as ref
-from .gemm_plan import PLAN as _PLAN
+from .gemm_plan import PLAN as _PLAN, TAIL as _TAIL
 from .kv_layout import allocate_kv_cache, bytes_per_block, kv_cache_shapes  # noqa: F401
 
 _SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C.so")
@@ -256,7 +256,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if bias is None and _PLAN.table and x.is_cuda and x.dim() == 2:
         s = _PLAN.splits_for(x.shape[0], weight.shape[0], weight.shape[1], False)
         if s and _tile_operand_ok(x, weight):
-            return hip().dense_gemm256(x, weight, False, s, out)
+            return hip().dense_gemm256(x, weight, False, 1, out, True) if s == _TAIL else hip().dense_gemm256(x, weight, False, s, out)
     if out is not None:
         return torch.mm(x, weight.t(), out=out) if bias is None else torch.addmm(bias, x, weight.t(), out=out)
     return torch.nn.functional.linear(x, weight, bias)
@@ -287,7 +287,7 @@ def linear_swiglu(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         s = _PLAN.splits_for(x.shape[0], weight.shape[0], weight.shape[1], True)
         if s is not None:
             if s and _tile_operand_ok(x, weight):
-                return hip().dense_gemm256(x, weight, True, s)
+                return hip().dense_gemm256(x, weight, True, 1, None, True) if s == _TAIL else hip().dense_gemm256(x, weight, True, s)
             return silu_and_mul(torch.nn.functional.linear(x, weight))
     if (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous()
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0

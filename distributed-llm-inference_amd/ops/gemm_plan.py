@@ -10,8 +10,10 @@ steps and of lightly loaded replicas — with bad spots that move with M (Llama-
 token counts in multiples of 256), so the table is keyed by the exact M the graphs will see; eager steps take the entry of
 the next bucket up.
 
-Candidates per (N, K, swiglu, M):  ``lib`` (hipBLASLt through torch, plus ``silu_and_mul`` for gate/up) and ``tile:S`` —
-the 256² tile with S K-slices (S = 1: no slabs; with the SwiGLU epilogue fused for gate/up).  Weights rotate through all
+Candidates per (N, K, swiglu, M):  ``lib`` (hipBLASLt through torch, plus ``silu_and_mul`` for gate/up), ``tile:S`` —
+the 256² tile with S K-slices (S = 1: no slabs; with the SwiGLU epilogue fused for gate/up) — and ``tile+tail``: the tile
+with only the REMAINDER of its last, partly filled round of one workgroup per CU cut into K-slices (a 7 × 112-tile
+gate/up GEMM is 3 rounds + 16 tiles: those 16 run as 128 slices next to each other instead of as a fourth round).  Weights rotate through all
 layers of the model while timing, so no candidate finds its matrix in the 256 MB infinity cache.  Rank 0's table is
 broadcast under TP: every rank of a group runs the same kernels.
 """
@@ -25,6 +27,8 @@ import torch
 
 ENABLED = os.environ.get("DLI_GEMM_TUNE", "1") != "0"
 MIN_ROWS = 65                 # at and below 64 rows the weight-streaming kernel (skinny_gemm.hip) has its own rules
+TAIL = 100                    # table value: plain tiles for the whole rounds, K-split remainder (dense_gemm256 split_tail)
+NUM_CU = 256
 
 
 class GemmPlan:
@@ -54,6 +58,17 @@ class GemmPlan:
         return n % 2 == 0 and k % 64 == 0 and n_out % (128 if swiglu else 256) == 0 and n * k * 2 < 2 ** 32
 
     @staticmethod
+    def tail_slices(m: int, n: int, k: int, swiglu: bool) -> int:
+        """K-slices the remainder tiles would be cut into (0: nothing to cut) — ``dense_gemm256_tail_plan`` in gemm256.hip."""
+        n_out = n // 2 if swiglu else n
+        tiles = (m + 255) // 256 * (n_out // (128 if swiglu else 256))
+        r = tiles % NUM_CU
+        if r == 0 or tiles < NUM_CU or r > NUM_CU // 2:
+            return 0
+        s = min(8, NUM_CU // r, k // 64 // 4)
+        return s if s >= 2 else 0
+
+    @staticmethod
     def candidates(m: int, n: int, k: int, swiglu: bool) -> list:
         n_out = n // 2 if swiglu else n
         tiles = (m + 255) // 256 * (n_out // (128 if swiglu else 256))
@@ -62,6 +77,8 @@ class GemmPlan:
         while s <= 16 and s <= k // 256 and tiles * s <= 768:
             out.append(s)
             s *= 2
+        if GemmPlan.tail_slices(m, n, k, swiglu):
+            out.append(TAIL)
         return out
 
     @torch.inference_mode()
@@ -88,6 +105,8 @@ class GemmPlan:
                 for s in self.candidates(m, n, k, swiglu):
                     if s == 0:
                         fn = (lambda w: silu_and_mul(F.linear(x, w))) if swiglu else (lambda w: F.linear(x, w))
+                    elif s == TAIL:
+                        fn = lambda w: lib.dense_gemm256(x, w, swiglu, 1, None, True)
                     else:
                         fn = lambda w, s=s: lib.dense_gemm256(x, w, swiglu, s)
                     times[s] = self._time(fn, weights)
@@ -95,8 +114,10 @@ class GemmPlan:
                 if best != 0 and times[best] > 0.97 * times[0]:
                     best = 0                                 # the library keeps ties: fewer moving parts
                 entry[m] = best
-                rep[m] = {"lib_us": round(times[0], 1), "best": "lib" if best == 0 else f"tile:{best}",
-                          "best_us": round(times[best], 1)}
+                rep[m] = {"lib_us": round(times[0], 1), "best_us": round(times[best], 1),
+                          "best": "lib" if best == 0 else "tile+tail" if best == TAIL else f"tile:{best}"}
+                if TAIL in times:
+                    rep[m]["tail_us"], rep[m]["tile1_us"] = round(times[TAIL], 1), round(times[1], 1)
             if entry:
                 entry["_sorted"] = sorted(entry)
                 self.table[(n, k, swiglu)] = entry

@@ -417,6 +417,32 @@ def test_dense_gemm256_split_k_swiglu(M, I, K, ks):
     assert (got - want).abs().max() / want.abs().max() < 1.5e-2
 
 
+@pytest.mark.parametrize("M,N,K,swiglu", [(2816, 6144, 4096, False), (1792, 28672, 4096, True), (1200, 28672, 4096, True),
+                                           (2100, 8192, 1024, False), (512, 4096, 4096, False)])
+def test_dense_gemm256_split_tail_matches_fp32_reference_and_the_plain_tiles(M, N, K, swiglu):
+    """Whole rounds of one tile per CU as plain tiles, the remainder tiles K-split into compact fp32 slabs + a per-tile
+    reduce (`gemm256_kernel` RANGE mode, `splitk_reduce_tiles_kernel`): every output element is written exactly once (the
+    result buffer starts as NaN), ragged last row tiles included; the last case has no remainder to cut (plain path)."""
+    from dli_amd.ops.gemm_plan import GemmPlan
+    x = _bf(M, K, seed=75)
+    w = _bf(N, K, seed=76, scale=0.05)
+    n_out = N // 2 if swiglu else N
+    out = torch.full((M, n_out), float("nan"), device=DEV, dtype=torch.bfloat16)
+    got = ops.hip().dense_gemm256(x, w, swiglu, 1, out, True).float()
+    h = x.float() @ w.float().t()
+    want = torch.nn.functional.silu(h[:, :n_out]) * h[:, n_out:] if swiglu else h
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() / want.abs().max() < 1.5e-2
+    plain = ops.hip().dense_gemm256(x, w, swiglu, 1).float()
+    assert (got - plain).abs().max() / want.abs().max() < 1e-2
+    cut = GemmPlan.tail_slices(M, N, K, swiglu)
+    assert (cut >= 2) == (M != 512)
+    if not cut:
+        assert torch.equal(got, plain)
+    else:                                                   # the whole rounds are the very same tiles: most rows × columns bit-equal
+        assert (got == plain).float().mean() > 0.5
+
+
 def test_dense_gemm256_identity_check_with_asymmetric_weights():
     """A = I with an asymmetric W: catches a transposed or permuted C write that symmetric data would hide."""
     K = N = 256
