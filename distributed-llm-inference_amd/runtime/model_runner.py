@@ -104,10 +104,17 @@ class ModelRunner:
         reserve = max(3 * (act + logits), 4 << 30) + (2 << 30)       # + graph pools
         budget = free - (total * (1.0 - c.cache.gpu_memory_utilization)) - reserve
         n_dev = max(torch.cuda.device_count(), 1)
-        if self.ctx.distributed and n_dev < self.ctx.tp_size:
-            # rehearsal mode: several ranks of the group live on this device and size their caches at the same time
-            sharing = (self.ctx.tp_size + n_dev - 1) // n_dev
-            budget = (budget - (sharing - 1) * reserve) / sharing
+        # rehearsal mode: several ranks (of a TP group, or data-parallel replicas of a job started with DLI_SHARE_GPU=1) live
+        # on this device and size their caches at the same time
+        from . import launch
+        group = self.ctx.tp_size if self.ctx.distributed else 1
+        job = int(os.environ.get("WORLD_SIZE", "1")) if launch.share_gpu_requested() else 1
+        sharing = (max(group, job) + n_dev - 1) // n_dev
+        if sharing > 1:
+            # whatever the others have loaded so far: an equal share of the device minus what THIS rank holds besides its cache
+            mine = torch.cuda.memory_allocated(self.device)
+            budget = min((budget - (sharing - 1) * reserve) / sharing,
+                         total * c.cache.gpu_memory_utilization / sharing - mine - reserve)
         n = int(budget // per_block)
         if n < self.max_blocks_per_seq:
             raise RuntimeError(f"not enough HBM for the KV cache: {budget / 2**30:.1f} GiB left after weights")
