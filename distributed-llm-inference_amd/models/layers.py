@@ -267,7 +267,7 @@ class VocabParallelEmbedding(nn.Module):
         self.per = self.vocab_padded // ctx.tp_size
 
     def forward(self, ids: torch.Tensor):
-        if self.ctx.tp_size == 1:
+        if self.ctx.solo:
             return F.embedding(ids, self.weight.data)
         lo = self.ctx.tp_rank * self.per
         local = ids - lo

@@ -38,6 +38,11 @@ class ParallelContext:
     # same bytes — the rank's GEMM / attention shapes, kernel count and host work per step are the real ones, the link
     # time is not.  Measures what one GPU of an 8-GPU replica has to do, on the one GPU there is.
     emulated: bool = False
+    # A TP "group" of ONE rank that still goes through the library for every collective (tp_size == 1): on a one-GPU box
+    # this is as much of the RCCL path as can execute — communicator set-up, the stream-ordered calls, their capture in
+    # the decode / mixed-step hipGraphs, RCCL on the side stream of the GEMM / all-reduce pipeline, pipelined stepping
+    # with an `nccl` device group (tests/test_rccl_gpu.py).  Two ranks on one device are refused by RCCL itself.
+    one_rank_group: bool = False
     # Sequence-parallel norms (set per forward pass by the model, see `sp_wanted`): the reductions that follow the
     # row-parallel GEMMs are fused with the residual add + RMSNorm and run on this rank's T / tp rows only
     # (`CustomAllReduce.all_reduce_add_norm`); every rank then carries the residual stream of ITS rows only, so all
@@ -57,7 +62,12 @@ class ParallelContext:
     @property
     def distributed(self) -> bool:
         """More than one process takes part (False for a single rank and for an emulated rank)."""
-        return self.tp_size > 1 and not self.emulated
+        return (self.tp_size > 1 or self.one_rank_group) and not self.emulated
+
+    @property
+    def solo(self) -> bool:
+        """No collective of any kind: one rank, no group."""
+        return self.tp_size == 1 and not self.one_rank_group
 
     @property
     def ep_rank(self) -> int:
@@ -67,7 +77,7 @@ class ParallelContext:
     def device_backend(self) -> str:
         if self.emulated:
             return "emulated"
-        if self.tp_size == 1 or self.group is None:
+        if self.solo or self.group is None:
             return "none"
         return dist.get_backend(self.group)
 
@@ -96,7 +106,7 @@ class ParallelContext:
                 and x.is_contiguous() and x.numel() % 8 == 0 and x.data_ptr() % 16 == 0 and self.device_backend != "nccl")
 
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
-        if self.tp_size == 1:
+        if self.solo:
             return x
         c = self.comm
         if self.emulated:
@@ -129,7 +139,7 @@ class ParallelContext:
         """Row exchange: ``x`` is ``[sum(in_rows), …]`` with ``in_rows[r]`` consecutive rows for TP rank r; returns
         ``[sum(out_rows), …]`` with ``out_rows[r]`` rows received from rank r (``dist.all_to_all_single``: RCCL on
         GPUs).  The split sizes are host integers — the caller has exchanged the counts beforehand."""
-        if self.tp_size == 1:
+        if self.solo:
             return x
         assert not self.emulated, "an emulated rank has no peers to exchange rows with (ep_a2a_min_tokens must be 0)"
         out = torch.empty((int(sum(out_rows)),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -142,7 +152,7 @@ class ParallelContext:
 
     def all_gather_last_dim(self, x: torch.Tensor) -> torch.Tensor:
         """[..., n] on every rank → [..., tp·n] ordered by rank."""
-        if self.tp_size == 1:
+        if self.solo:
             return x
         lead, n = x.shape[:-1], x.shape[-1]
         x2 = x.reshape(-1, n).contiguous()
@@ -166,7 +176,7 @@ class ParallelContext:
 
     def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
         """``[n, …]`` on every rank → ``[tp·n, …]`` ordered by rank (equal row counts)."""
-        if self.tp_size == 1:
+        if self.solo:
             return x
         x = x.contiguous()
         self.comm["ag_calls"] += 1
@@ -242,18 +252,19 @@ def init_distributed(backend: str = "auto", device: Optional[torch.device] = Non
 def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None, with_cpu_group: bool = True,
                     custom_all_reduce: bool = False, device: Optional[torch.device] = None,
                     all_groups: Optional[list] = None, device_backend: Optional[str] = None,
-                    ep_a2a_min_tokens: int = 0, ar_tuning_rows: Optional[list] = None) -> ParallelContext:
+                    ep_a2a_min_tokens: int = 0, ar_tuning_rows: Optional[list] = None,
+                    one_rank_group: bool = False) -> ParallelContext:
     """TP group over ``ranks`` (default: the whole world).  Must be called by every rank of the world.
 
     ``all_groups``: every TP group of the job (list of rank lists, ``ranks`` among them) when the world holds several
     replicas — ``dist.new_group`` is collective over the WORLD, so each rank creates all groups in the same order and
     keeps its own.  ``device_backend`` overrides the backend of the device group (``"gloo"`` when the RCCL probe
     failed: the job still runs, through the custom kernels and host-staged collectives)."""
-    if tp_size == 1:
+    if tp_size == 1 and not one_rank_group:
         return ParallelContext()
     assert dist.is_initialized(), "call init_distributed() first"
     if ranks is None:
-        ranks = list(range(dist.get_world_size()))
+        ranks = list(range(dist.get_world_size())) if not one_rank_group else [dist.get_rank()]
     assert len(ranks) == tp_size, f"TP group needs {tp_size} ranks, got {ranks}"
     assert ep_size in (1, tp_size), "expert parallelism is either off or spans the TP group"
     group = cpu_group = None
@@ -267,8 +278,9 @@ def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None
             group, cpu_group = g, cg
     assert group is not None, f"{ranks} is not one of the groups {all_groups}"
     ctx = ParallelContext(tp_size=tp_size, tp_rank=ranks.index(dist.get_rank()), group=group, cpu_group=cpu_group,
-                          ep_size=ep_size, ep_a2a_min_tokens=ep_a2a_min_tokens if ep_size > 1 else 0)
-    if custom_all_reduce and device is not None and device.type == "cuda":
+                          ep_size=ep_size, ep_a2a_min_tokens=ep_a2a_min_tokens if ep_size > 1 else 0,
+                          one_rank_group=one_rank_group and tp_size == 1)
+    if custom_all_reduce and tp_size > 1 and device is not None and device.type == "cuda":
         from .custom_all_reduce import CustomAllReduce
         ar = CustomAllReduce.create(ctx, device, tuning_rows=ar_tuning_rows)
         # all or nothing: one rank without the fast path while its peers wait in the kernels' flag barriers is a hang
