@@ -91,8 +91,10 @@ class ParallelContext:
         if self.emulated:
             return nbytes > (256 << 10)
         ar = self.custom_ar
-        floor = int(os.environ.get("DLI_SP_MIN_BYTES", "0")) or ar.one_shot_max_bytes if ar is not None else 0
-        return ar is not None and ar.enabled and ar.fits(nbytes) and nbytes > floor
+        if ar is None or not ar.enabled or not ar.fits(nbytes):
+            return False
+        floor = int(os.environ.get("DLI_SP_MIN_BYTES", "0")) or ar.one_shot_max_bytes     # the env value: tests with tiny models
+        return nbytes > floor
 
     def sp_rows(self, T: int):
         """This rank's row range of a sequence-parallel step."""
