@@ -21,6 +21,8 @@
 //
 // KV8: pages hold OCP e4m3 (K chunks are 64 wide, see kv_layout); values are widened to bf16 in
 // registers, the per-tensor scales are folded into the softmax scale (K) and the epilogue (V).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -46,21 +48,27 @@ template <bool KV8>
 struct KLoader {
   // bf16: page [4][32 tok][32]:  element offset ((c*32 + rt*16 + col)*32 + 8g)
   // fp8 : page [2][32 tok][64]:  byte offset ((c2*32 + rt*16 + col)*64 + 16g) holds k-steps 2c2, 2c2+1
+  // NT: streaming (non-temporal) loads — decode reads every K/V byte exactly once per step
+  template <bool NT = false>
   static __device__ __forceinline__ void load(const void* page, int col, int g, bf16x8 (&kf)[2][4]) {
     if constexpr (!KV8) {
       const uint16_t* p = reinterpret_cast<const uint16_t*>(page) + col * 32 + g * 8;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) kf[rt][c] = *reinterpret_cast<const bf16x8*>(p + (c * 32 + rt * 16) * 32);
+        for (int c = 0; c < 4; ++c) {
+          const bf16x8* src = reinterpret_cast<const bf16x8*>(p + (c * 32 + rt * 16) * 32);
+          kf[rt][c] = NT ? __builtin_nontemporal_load(src) : *src;
+        }
     } else {
       const uint8_t* p = reinterpret_cast<const uint8_t*>(page) + col * 64 + g * 16;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(p + (c2 * 32 + rt * 16) * 64);
-          const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+          const u32x4* src = reinterpret_cast<const u32x4*>(p + (c2 * 32 + rt * 16) * 64);
+          const u32x4 raw = NT ? __builtin_nontemporal_load(src) : *src;
+          const uint32_t w[4] = {raw[0], raw[1], raw[2], raw[3]};
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             bf16x8 f;
@@ -79,15 +87,17 @@ struct KLoader {
 };
 
 // V fragment for d tile n (rows 16n..16n+15) of lane (col, g): slots 8g..8g+7 of row d = 16n + col.
-template <bool KV8>
+template <bool KV8, bool NT = false>
 __device__ __forceinline__ bf16x8 load_v(const void* page, int n, int col, int g) {
   if constexpr (!KV8) {
-    return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(page) + (16 * n + col) * 32 + 8 * g);
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(page) + (16 * n + col) * 32 + 8 * g);
+    return NT ? __builtin_nontemporal_load(src) : *src;
   } else {
-    const uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(page) + (16 * n + col) * 32 + 8 * g);
+    const u32x2* src = reinterpret_cast<const u32x2*>(reinterpret_cast<const uint8_t*>(page) + (16 * n + col) * 32 + 8 * g);
+    const u32x2 raw = NT ? __builtin_nontemporal_load(src) : *src;
     bf16x8 f;
-    fp8x4_to_bf16(raw.x, f, 0);
-    fp8x4_to_bf16(raw.y, f, 4);
+    fp8x4_to_bf16(raw[0], f, 0);
+    fp8x4_to_bf16(raw[1], f, 4);
     return f;
   }
 }
@@ -166,7 +176,7 @@ __device__ __forceinline__ bf16x8 softmax_step(f32x4 (&s)[2], int tok0, int limi
 // Partial results: `part_o[(p·Hq + head)·128 + d]`, `part_ml[(p·Hq + head)·2 + {m, l}]` with p = slot (WL) or
 // seq·num_splits + split; decode_reduce_kernel combines them per sequence.
 // ==================================================================================================
-template <bool KV8, bool WL>
+template <bool KV8, bool WL, bool NT = false>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
     const uint16_t* __restrict__ q, int64_t q_stride, const void* __restrict__ k_cache, const void* __restrict__ v_cache,
     const int* __restrict__ block_tables, int max_blocks, const int* __restrict__ seq_lens, uint16_t* __restrict__ out,
@@ -230,10 +240,10 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     if (b + 4 < b_end) blk_next = bt[b + 4];
     const int64_t page = ((int64_t)blk_cur * Hkv + kvh) * (PAGE_ELEMS * ESZ);
     bf16x8 kf[2][4];
-    KLoader<KV8>::load(kc + page, col, g, kf);
+    KLoader<KV8>::template load<NT>(kc + page, col, g, kf);
     bf16x8 vf[8];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) vf[n] = load_v<KV8>(vc + page, n, col, g);
+    for (int n = 0; n < 8; ++n) vf[n] = load_v<KV8, NT>(vc + page, n, col, g);
 
     f32x4 s[2];
 #pragma unroll
@@ -572,6 +582,11 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
 }
 
 // ---- launchers -------------------------------------------------------------------------------------
+// Decode reads every K/V byte exactly once per step: the loads are NON-TEMPORAL (streaming cache policy), so the pages do not
+// displace what the GEMMs keep in L2 / the infinity cache and are themselves not written into them: 5.95 → 6.60 TB/s on the
+// trace's length mix at B = 1024 (profiles/ab_decode_nt_r3.jsonl).  DLI_DECODE_NT=0: plain loads (A/B knob).
+static const bool g_decode_nt = std::getenv("DLI_DECODE_NT") == nullptr || std::atoi(std::getenv("DLI_DECODE_NT")) != 0;
+
 void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                          const int* block_tables, int max_blocks, const int* seq_lens, void* out, int64_t out_stride,
                          float* part_o, float* part_ml, int num_seqs, int Hq, int Hkv, int num_splits, float scale,
@@ -582,14 +597,13 @@ void launch_paged_decode(const void* q, int64_t q_stride, const void* k_cache, c
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
   const size_t lds = (size_t)(4 * G * (HD + 4) + 8 * G) * sizeof(float);
   dim3 grid(Hkv, num_seqs, num_splits);
-  if (kv_fp8)
-    hipLaunchKernelGGL((paged_decode_kernel<true, false>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
-                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
-                       num_splits, scale_log2, v_scale, kv_scales, nullptr, nullptr);
-  else
-    hipLaunchKernelGGL((paged_decode_kernel<false, false>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
-                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,
-                       num_splits, scale_log2, 1.f, nullptr, nullptr, nullptr);
+#define DLI_DECODE_GO(KV8_, NT_)                                                                                              \
+  hipLaunchKernelGGL((paged_decode_kernel<KV8_, false, NT_>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache, \
+                     v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv,           \
+                     num_splits, scale_log2, KV8_ ? v_scale : 1.f, KV8_ ? kv_scales : nullptr, nullptr, nullptr)
+  if (kv_fp8) { if (g_decode_nt) DLI_DECODE_GO(true, true); else DLI_DECODE_GO(true, false); }
+  else { if (g_decode_nt) DLI_DECODE_GO(false, true); else DLI_DECODE_GO(false, false); }
+#undef DLI_DECODE_GO
   if (num_splits > 1)
     hipLaunchKernelGGL(decode_reduce_kernel, dim3(num_seqs, Hq), dim3(128), 0, stream, part_o, part_ml, (uint16_t*)out,
                        out_stride, Hq, num_splits, kv_fp8 ? v_scale : 1.f, kv_fp8 ? kv_scales : nullptr, Hkv, nullptr, nullptr);
@@ -608,14 +622,13 @@ void launch_paged_decode_worklist(const void* q, int64_t q_stride, const void* k
   const float scale_log2 = scale * 1.4426950408889634f * (kv_fp8 ? k_scale : 1.f);
   const size_t lds = (size_t)(4 * G * (HD + 4) + 8 * G) * sizeof(float);
   dim3 grid(Hkv, items);
-  if (kv_fp8)
-    hipLaunchKernelGGL((paged_decode_kernel<true, true>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
-                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv, 1,
-                       scale_log2, v_scale, kv_scales, (const int4*)work, counts);
-  else
-    hipLaunchKernelGGL((paged_decode_kernel<false, true>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,
-                       v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv, 1,
-                       scale_log2, 1.f, nullptr, (const int4*)work, counts);
+#define DLI_DECODE_GO(KV8_, NT_)                                                                                              \
+  hipLaunchKernelGGL((paged_decode_kernel<KV8_, true, NT_>), grid, dim3(256), lds, stream, (const uint16_t*)q, q_stride, k_cache,  \
+                     v_cache, block_tables, max_blocks, seq_lens, (uint16_t*)out, out_stride, part_o, part_ml, Hq, Hkv, 1,        \
+                     scale_log2, KV8_ ? v_scale : 1.f, KV8_ ? kv_scales : nullptr, (const int4*)work, counts)
+  if (kv_fp8) { if (g_decode_nt) DLI_DECODE_GO(true, true); else DLI_DECODE_GO(true, false); }
+  else { if (g_decode_nt) DLI_DECODE_GO(false, true); else DLI_DECODE_GO(false, false); }
+#undef DLI_DECODE_GO
   if (reds > 0)
     hipLaunchKernelGGL(decode_reduce_kernel, dim3(reds, Hq), dim3(128), 0, stream, part_o, part_ml, (uint16_t*)out,
                        out_stride, Hq, 1, kv_fp8 ? v_scale : 1.f, kv_fp8 ? kv_scales : nullptr, Hkv, (const int4*)red, counts);
