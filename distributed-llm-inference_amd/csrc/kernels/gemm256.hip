@@ -42,6 +42,10 @@ namespace g256 {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int TILE_BYTES = TM * TK * 2;        // one operand tile of one K-step: 32 KB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+#ifndef DLI_G256_W_AUX
+#define DLI_G256_W_AUX 0
+#endif
+constexpr int G256_W_AUX = DLI_G256_W_AUX;     // cache policy of the W-operand DMA; 2 = nt was measured: neutral for one row tile, 3 % SLOWER at M ≥ 2304 (the panel IS re-used by the row tiles of an XCD: profiles/ab_g256_wnt_r3.txt)
 
 enum { EPI_SWIGLU = 0, EPI_SCATTER = 1, EPI_SCATTER_SPLITK = 2, EPI_PLAIN = 3, EPI_PLAIN_SPLITK = 4, EPI_SWIGLU_SPLITK = 5 };
 // The two dense split-K epilogues (mid-M GEMMs: one or two row tiles cannot fill 256 CUs, so K is cut into slices) store
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
       (gptr_t)(Ab + a_src[h_][jj] + ((kt_) + kt0) * (TK * 2)), (lptr_t)(lds + (buf_) * TILE_BYTES + a_dst[h_][jj]), 16, 0, 0);
 #define G256_STAGE_B(kt_, buf_, h_)                                                                                  \
   _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) __builtin_amdgcn_global_load_lds(                                  \
-      (gptr_t)(Wb + b_src[h_][jj] + ((kt_) + kt0) * (TK * 2)), (lptr_t)(lds + STAGE_BYTES + (buf_) * TILE_BYTES + b_dst[h_][jj]), 16, 0, 0);
+      (gptr_t)(Wb + b_src[h_][jj] + ((kt_) + kt0) * (TK * 2)), (lptr_t)(lds + STAGE_BYTES + (buf_) * TILE_BYTES + b_dst[h_][jj]), 16, 0, G256_W_AUX);
   // fragment reads: A rows wr·128 + m·16 + col, B rows wc·64 + n·16 + col; chunk ks·4 + g of the 64-wide K-step
   // (row offsets that are multiples of 8 rows leave the swizzle term alone: two base addresses per operand — one per
   //  32-wide k half — and compile-time immediates for everything else)
