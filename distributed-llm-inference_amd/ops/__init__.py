@@ -315,6 +315,19 @@ def rope_and_cache(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: Optional
                                head_dim, k_scale, v_scale)
 
 
+# Mixed steps: prefill tiles next to the decode rows on a side stream (same-box serving A/B: TPOT p50 39.4 → 38.4 ms,
+# profiles/bench_r3aj_concurrent_attention_{0,1}.json).  DLI_CONCURRENT_ATTN=0: one after the other.
+CONCURRENT_ATTN = os.environ.get("DLI_CONCURRENT_ATTN", "1") != "0"
+_ATTN_STREAMS: dict = {}
+
+
+def _attn_stream(device):
+    key = (device.type, device.index)
+    if key not in _ATTN_STREAMS:
+        _ATTN_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _ATTN_STREAMS[key]
+
+
 def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, meta: AttnMetadata,
                     num_heads: int, num_kv_heads: int, head_dim: int, scale: float,
                     k_scale: float = 1.0, v_scale: float = 1.0, out: Optional[torch.Tensor] = None,
@@ -329,6 +342,19 @@ def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
         if out is None:
             out = torch.empty(T, num_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
         lib = hip()
+        side = None
+        if CONCURRENT_ATTN and meta.num_prefill_tiles > 0 and (meta.decode_items > 0 or meta.num_decode > 0):
+            # mixed step: the prefill tiles (MFMA / VALU-bound, a few hundred workgroups) run on a side stream next to the
+            # decode rows (HBM-bound) — disjoint rows of `out`; inside a capture the side stream forks from and joins the
+            # capturing stream, so the step's graph gets two parallel branches per layer
+            main = torch.cuda.current_stream()
+            side = _attn_stream(qkv.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                lib.paged_attention_prefill(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
+                                            meta.query_start_loc, meta.prefill_tile_seq, meta.prefill_tile_q0,
+                                            meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale, kv_scales,
+                                            meta.counts if meta.counts_on_device else None)
         if meta.decode_items > 0:
             lib.paged_attention_decode_worklist(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
                                                 meta.decode_work, meta.decode_red, meta.counts, meta.decode_items,
@@ -338,7 +364,9 @@ def paged_attention(qkv: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
             lib.paged_attention_decode(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens, meta.num_decode,
                                        num_heads, num_kv_heads, scale, meta.decode_splits, meta.decode_workspace,
                                        k_scale, v_scale, kv_scales)
-        if meta.num_prefill_tiles > 0:
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        elif meta.num_prefill_tiles > 0:
             lib.paged_attention_prefill(out, q, k_cache, v_cache, meta.block_tables, meta.seq_lens,
                                         meta.query_start_loc, meta.prefill_tile_seq, meta.prefill_tile_q0,
                                         meta.num_prefill_tiles, num_heads, num_kv_heads, scale, k_scale, v_scale, kv_scales,
