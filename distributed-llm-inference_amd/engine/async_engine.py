@@ -204,11 +204,16 @@ class AsyncEngine:
             try:
                 msg = self._chan.recv()
             except (EOFError, OSError):
-                self._loop.call_soon_threadsafe(self._on_dead, "engine channel closed")
+                msg = None
+            try:
+                if msg is None:
+                    self._loop.call_soon_threadsafe(self._on_dead, "engine channel closed")
+                    return
+                if msg[0] == "bye":
+                    return
+                self._loop.call_soon_threadsafe(self._dispatch, msg)
+            except RuntimeError:                             # the server's event loop is gone (shutdown): nobody to tell
                 return
-            if msg[0] == "bye":
-                return
-            self._loop.call_soon_threadsafe(self._dispatch, msg)
 
     def _on_dead(self, why: str):
         self._dead = why

@@ -40,6 +40,39 @@ def _now_iso() -> str:
     return datetime.now(timezone.utc).isoformat().replace("+00:00", "Z")
 
 
+
+class StopMatcher:
+    """Stop strings over the detokenised stream (Ollama ``options.stop``, OpenAI ``stop``).  ``feed`` returns the text that
+    may be sent now — everything except a suffix that could still grow into a stop string — and whether a stop string
+    was completed (the text before it is returned, the string itself is not, as both APIs specify)."""
+
+    def __init__(self, stops):
+        self.stops = [s for s in stops if isinstance(s, str) and s]
+        self.hold = ""
+
+    def __bool__(self):
+        return bool(self.stops)
+
+    def feed(self, piece: str):
+        buf = self.hold + piece
+        hits = [i for i in (buf.find(s) for s in self.stops) if i >= 0]
+        if hits:
+            self.hold = ""
+            return buf[:min(hits)], True
+        keep = 0
+        for s in self.stops:
+            for n in range(min(len(s) - 1, len(buf)), keep, -1):
+                if buf.endswith(s[:n]):
+                    keep = n
+                    break
+        self.hold = buf[len(buf) - keep:] if keep else ""
+        return (buf[:len(buf) - keep] if keep else buf), False
+
+    def flush(self) -> str:
+        out, self.hold = self.hold, ""
+        return out
+
+
 class ApiServer:
     def __init__(self, cfg: EngineConfig, engine_mode: str = "thread", served_name: str | None = None,
                  default_max_tokens: int = 128, engine=None, max_pending_requests: int = 0):
@@ -77,6 +110,15 @@ class ApiServer:
                               top_k=int(pick("top_k", default=0)), max_tokens=int(max_tokens),
                               ignore_eos=bool(pick("ignore_eos", default=False)),
                               seed=None if seed is None else int(seed))
+
+    @staticmethod
+    def _stops(body: dict) -> list:
+        v = body.get("stop")
+        if v is None:
+            v = (body.get("options") or {}).get("stop")
+        if v is None:
+            return []
+        return [v] if isinstance(v, str) else [x for x in v if isinstance(x, str)][:16]
 
     def _rid(self, prefix: str) -> str:
         return f"{prefix}-{next(self._ids)}"
@@ -132,6 +174,7 @@ class ApiServer:
         rid = self._rid("gen")
         t0 = time.perf_counter_ns()
         dec = self.tokenizer.stream_decoder()
+        stops = StopMatcher(self._stops(body))
         t_first = None
         out_ids: list[int] = []
         reason = "stop"
@@ -141,19 +184,30 @@ class ApiServer:
             await resp.prepare(request)                              # ack now: admission, not first token
             dumps = json.dumps
             try:
-                async for item in self._tracked(rid, ids, params):
-                    if item.token is not None:
-                        if t_first is None:
-                            t_first = time.perf_counter_ns()
-                        out_ids.append(item.token)
-                        piece = dec.step(item.token)
-                        await resp.write((dumps({"model": model, "created_at": _now_iso(), "response": piece,
-                                                 "done": False}) + "\n").encode())
-                    if item.finished:
-                        reason = item.reason or "stop"
-                        n_prompt = item.n_prompt
+                agen = self._tracked(rid, ids, params)
+                hit = False
+                try:
+                    async for item in agen:
+                        if item.token is not None:
+                            if t_first is None:
+                                t_first = time.perf_counter_ns()
+                            out_ids.append(item.token)
+                            piece = dec.step(item.token)
+                            if stops:
+                                piece, hit = stops.feed(piece)
+                            await resp.write((dumps({"model": model, "created_at": _now_iso(), "response": piece,
+                                                     "done": False}) + "\n").encode())
+                            if hit:                                  # a stop string is complete: the engine drops the request
+                                reason = "stop"
+                                break
+                        if item.finished:
+                            reason = item.reason or "stop"
+                            n_prompt = item.n_prompt
+                finally:
+                    await agen.aclose()                              # early exit (stop string, client gone): abort in the engine
                 t_end = time.perf_counter_ns()
-                tail = self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, dec.flush())
+                last = "" if hit else (stops.feed(dec.flush())[0] + stops.flush() if stops else dec.flush())
+                tail = self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, last)
                 await resp.write((dumps(tail) + "\n").encode())
                 await resp.write_eof()
             except (ConnectionResetError, asyncio.CancelledError):
@@ -161,17 +215,29 @@ class ApiServer:
             return resp
 
         text = []
-        async for item in self._tracked(rid, ids, params):
-            if item.token is not None:
-                if t_first is None:
-                    t_first = time.perf_counter_ns()
-                out_ids.append(item.token)
-                text.append(dec.step(item.token))
-            if item.finished:
-                reason = item.reason or "stop"
+        agen = self._tracked(rid, ids, params)
+        hit = False
+        try:
+            async for item in agen:
+                if item.token is not None:
+                    if t_first is None:
+                        t_first = time.perf_counter_ns()
+                    out_ids.append(item.token)
+                    piece = dec.step(item.token)
+                    if stops:
+                        piece, hit = stops.feed(piece)
+                    text.append(piece)
+                    if hit:
+                        reason = "stop"
+                        break
+                if item.finished:
+                    reason = item.reason or "stop"
+        finally:
+            await agen.aclose()
+        if not hit:
+            text.append(stops.feed(dec.flush())[0] + stops.flush() if stops else dec.flush())
         t_end = time.perf_counter_ns()
-        return web.json_response(self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end,
-                                                   "".join(text) + dec.flush()))
+        return web.json_response(self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, "".join(text)))
 
     @staticmethod
     def _ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, response_text):
@@ -220,6 +286,10 @@ class ApiServer:
         created = int(time.time())
         obj = "chat.completion" if chat else "text_completion"
         decs = [self.tokenizer.stream_decoder() for _ in range(n)]
+        # stop strings, per choice.  One choice: the request is dropped at the hit.  n > 1: the choice goes silent and
+        # reports finish_reason "stop"; its siblings share the stream and run on
+        stops = [StopMatcher(self._stops(body)) for _ in range(n)]
+        stopped = [False] * n
 
         def chunk(piece, finish=None, streaming=True, index=0):
             if chat:
@@ -233,17 +303,34 @@ class ApiServer:
         if body.get("stream"):
             resp = web.StreamResponse(headers={"Content-Type": "text/event-stream", "Cache-Control": "no-cache"})
             await resp.prepare(request)
-            n_out = n_prompt = 0
-            async for item in self._tracked(rid, ids, params, n):
-                finish = None
-                dec = decs[item.choice]
-                if item.finished:
-                    finish = "length" if item.reason == "length" else (item.reason or "stop")
-                    n_out, n_prompt = n_out + item.n_out, item.n_prompt
-                piece = dec.step(item.token) if item.token is not None else ""
-                if item.finished:
-                    piece += dec.flush()
-                await resp.write(("data: " + json.dumps(chunk(piece, finish, index=item.choice)) + "\n\n").encode())
+            n_out = n_prompt = seen = 0
+            agen = self._tracked(rid, ids, params, n)
+            try:
+                async for item in agen:
+                    finish = None
+                    c = item.choice
+                    seen += item.token is not None
+                    dec = decs[c]
+                    if item.finished:
+                        finish = "length" if item.reason == "length" else (item.reason or "stop")
+                        n_out, n_prompt = n_out + item.n_out, item.n_prompt
+                    if stopped[c]:
+                        continue
+                    piece = dec.step(item.token) if item.token is not None else ""
+                    if item.finished:
+                        piece += dec.flush()
+                    if stops[c]:
+                        piece, stopped[c] = stops[c].feed(piece)
+                        if stopped[c]:
+                            finish = "stop"
+                        elif item.finished:
+                            piece += stops[c].flush()
+                    await resp.write(("data: " + json.dumps(chunk(piece, finish, index=c)) + "\n\n").encode())
+                    if stopped[c] and n == 1:
+                        n_out, n_prompt = seen, len(ids)
+                        break
+            finally:
+                await agen.aclose()
             if (body.get("stream_options") or {}).get("include_usage"):
                 usage = {"id": rid, "object": obj, "created": created, "model": model, "choices": [],
                          "usage": {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}}
@@ -253,15 +340,37 @@ class ApiServer:
             return resp
 
         pieces, finish, n_out, n_prompt = [[] for _ in range(n)], ["stop"] * n, 0, len(ids)
-        async for item in self._tracked(rid, ids, params, n):
-            if item.token is not None:
-                pieces[item.choice].append(decs[item.choice].step(item.token))
-            if item.finished:
-                finish[item.choice] = "length" if item.reason == "length" else (item.reason or "stop")
-                n_out, n_prompt = n_out + item.n_out, item.n_prompt or n_prompt
-        out = chunk("".join(pieces[0]) + decs[0].flush(), finish[0], streaming=False)
+        counted = [0] * n
+        agen = self._tracked(rid, ids, params, n)
+        try:
+            async for item in agen:
+                c = item.choice
+                if item.finished:
+                    n_out, n_prompt = n_out + item.n_out, item.n_prompt or n_prompt
+                if stopped[c]:
+                    continue
+                if item.token is not None:
+                    counted[c] += 1
+                    piece = decs[c].step(item.token)
+                    if stops[c]:
+                        piece, stopped[c] = stops[c].feed(piece)
+                    pieces[c].append(piece)
+                if stopped[c]:
+                    finish[c] = "stop"
+                    if n == 1:
+                        n_out = counted[0]
+                        break
+                elif item.finished:
+                    finish[c] = "length" if item.reason == "length" else (item.reason or "stop")
+        finally:
+            await agen.aclose()
+        for i in range(n):
+            if not stopped[i]:
+                tail = decs[i].flush()
+                pieces[i].append(stops[i].feed(tail)[0] + stops[i].flush() if stops[i] else tail)
+        out = chunk("".join(pieces[0]), finish[0], streaming=False)
         for i in range(1, n):
-            out["choices"].append(chunk("".join(pieces[i]) + decs[i].flush(), finish[i], streaming=False, index=i)["choices"][0])
+            out["choices"].append(chunk("".join(pieces[i]), finish[i], streaming=False, index=i)["choices"][0])
         out["usage"] = {"prompt_tokens": n_prompt, "completion_tokens": n_out, "total_tokens": n_prompt + n_out}
         return web.json_response(out)
 

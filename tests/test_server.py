@@ -72,6 +72,45 @@ def test_api_generate_non_stream_and_options_and_seed():
     assert st == 400 and st2 == 400
 
 
+def test_stop_strings_cut_the_stream_and_release_the_request():
+    """Ollama `options.stop` / OpenAI `stop`: generation ends at the first stop string, the text before it is returned
+    and the string itself is not; a stop string that straddles two tokens is found; the request is dropped in the engine
+    (no stream left open)."""
+    from dli_amd.server.api_server import StopMatcher
+    m = StopMatcher(["END", "xy"])
+    got = [m.feed(p) for p in ("hel", "lo E", "N", "D wor")]
+    assert got == [("hel", False), ("lo ", False), ("", False), ("", True)]
+    m = StopMatcher(["ab"])
+    assert m.feed("xa") == ("x", False) and m.feed("c") == ("ac", False) and m.flush() == ""
+
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            p = {"prompt": "abc", "stream": False, "options": {"num_predict": 24, "temperature": 0}}
+            full = await (await s.post(base + "/api/generate", json=p)).json()
+            text = full["response"]
+            assert len(text) >= 6, text
+            stop = text[len(text) // 2: len(text) // 2 + 2]            # two characters from the middle
+            cut = text[:text.find(stop)]
+            a = await (await s.post(base + "/api/generate", json=dict(p, options=dict(p["options"], stop=[stop])))).json()
+            lines = []
+            async with s.post(base + "/api/generate", json=dict(p, stream=True, stop=[stop])) as r:
+                async for raw in r.content:
+                    lines.append(json.loads(raw))
+            o = await (await s.post(base + "/v1/completions", json={"prompt": "abc", "max_tokens": 24, "temperature": 0,
+                                                                     "stop": stop})).json()
+            for _ in range(50):                                      # the aborts are processed by the engine thread
+                if server.aengine.num_streams == 0:
+                    break
+                await asyncio.sleep(0.05)
+            return full, cut, a, lines, o, server.aengine.num_streams
+    full, cut, a, lines, o, open_streams = with_server(body)
+    assert a["response"] == cut and a["done_reason"] == "stop" and a["eval_count"] < full["eval_count"]
+    assert "".join(l["response"] for l in lines) == cut and lines[-1]["done"] and lines[-1]["done_reason"] == "stop"
+    assert o["choices"][0]["text"] == cut and o["choices"][0]["finish_reason"] == "stop"
+    assert o["usage"]["completion_tokens"] < full["eval_count"]
+    assert open_streams == 0
+
+
 def test_openai_completions_sse_and_usage_and_chat():
     async def body(server, base):
         async with aiohttp.ClientSession() as s:
