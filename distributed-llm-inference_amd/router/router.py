@@ -343,7 +343,7 @@ class Router:
 
     def app(self) -> web.Application:
         app = web.Application(client_max_size=64 << 20)
-        for path in ("/api/generate", "/v1/completions", "/v1/chat/completions"):
+        for path in ("/api/generate", "/api/chat", "/v1/completions", "/v1/chat/completions"):
             app.router.add_post(path, self.proxy)
         app.router.add_get("/health", self.health)
         app.router.add_get("/router/stats", self.stats)

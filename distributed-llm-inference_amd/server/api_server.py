@@ -158,13 +158,30 @@ class ApiServer:
             raise web.HTTPBadRequest(text=json.dumps({"error": f"invalid JSON body: {e}"}),
                                      content_type="application/json")
 
-    # ------------------------------------------------------------------ Ollama: /api/generate
-    async def api_generate(self, request: web.Request):
+    # ------------------------------------------------------------------ Ollama: /api/generate, /api/chat
+    async def api_chat(self, request: web.Request):
+        """Ollama chat API (what ``langchain_ollama.ChatOllama`` of the reference's notebooks calls,
+        ``/root/reference/notebooks/llm_requests.ipynb:53-57``): ``messages`` in, ``message`` pieces out, same NDJSON
+        framing and timing tail as ``/api/generate``."""
+        return await self.api_generate(request, chat=True)
+
+    async def api_generate(self, request: web.Request, chat: bool = False):
         body = await self._json(request)
-        prompt = body.get("prompt")
+        if chat:
+            msgs = body.get("messages")
+            if not isinstance(msgs, list) or not msgs or not all(isinstance(m, dict) for m in msgs):
+                return self._bad("'messages' must be a non-empty list of {role, content} objects")
+            prompt = "".join(f"{m.get('role', 'user')}: {m.get('content', '')}\n" for m in msgs) + "assistant: "
+        else:
+            prompt = body.get("prompt")
         if not isinstance(prompt, str):
             return self._bad("'prompt' must be a string")
         model = body.get("model") or self.served_name
+
+        def line(piece):                                             # one streamed record
+            if chat:
+                return {"model": model, "created_at": _now_iso(), "message": {"role": "assistant", "content": piece}, "done": False}
+            return {"model": model, "created_at": _now_iso(), "response": piece, "done": False}
         stream = body.get("stream", True)
         busy = self._overloaded()
         if busy is not None:
@@ -195,8 +212,7 @@ class ApiServer:
                             piece = dec.step(item.token)
                             if stops:
                                 piece, hit = stops.feed(piece)
-                            await resp.write((dumps({"model": model, "created_at": _now_iso(), "response": piece,
-                                                     "done": False}) + "\n").encode())
+                            await resp.write((dumps(line(piece)) + "\n").encode())
                             if hit:                                  # a stop string is complete: the engine drops the request
                                 reason = "stop"
                                 break
@@ -207,7 +223,7 @@ class ApiServer:
                     await agen.aclose()                              # early exit (stop string, client gone): abort in the engine
                 t_end = time.perf_counter_ns()
                 last = "" if hit else (stops.feed(dec.flush())[0] + stops.flush() if stops else dec.flush())
-                tail = self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, last)
+                tail = self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, last, chat)
                 await resp.write((dumps(tail) + "\n").encode())
                 await resp.write_eof()
             except (ConnectionResetError, asyncio.CancelledError):
@@ -237,19 +253,20 @@ class ApiServer:
         if not hit:
             text.append(stops.feed(dec.flush())[0] + stops.flush() if stops else dec.flush())
         t_end = time.perf_counter_ns()
-        return web.json_response(self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, "".join(text)))
+        return web.json_response(self._ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, "".join(text), chat))
 
     @staticmethod
-    def _ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, response_text):
+    def _ollama_tail(model, reason, ids, out_ids, t0, t_first, t_end, response_text, chat=False):
         t_first = t_first or t_end
+        text = {"message": {"role": "assistant", "content": response_text}} if chat else {"response": response_text}
         if reason == "shed":
             reason = "error: server overloaded, request shed after waiting too long for admission"
         if reason.startswith("error"):
-            return {"model": model, "created_at": _now_iso(), "response": "", "done": True, "done_reason": "error",
-                    "error": reason}
-        return {"model": model, "created_at": _now_iso(), "response": response_text, "done": True,
+            text = {"message": {"role": "assistant", "content": ""}} if chat else {"response": ""}
+            return {"model": model, "created_at": _now_iso(), **text, "done": True, "done_reason": "error", "error": reason}
+        return {"model": model, "created_at": _now_iso(), **text, "done": True,
                 "done_reason": "stop" if reason == "stop" else reason,
-                "context": list(ids) + out_ids, "total_duration": t_end - t0, "load_duration": 0,
+                **({} if chat else {"context": list(ids) + out_ids}), "total_duration": t_end - t0, "load_duration": 0,
                 "prompt_eval_count": len(ids), "prompt_eval_duration": t_first - t0,
                 "eval_count": len(out_ids), "eval_duration": t_end - t_first}
 
@@ -413,6 +430,7 @@ class ApiServer:
         app = web.Application(client_max_size=64 << 20)
         r = app.router
         r.add_post("/api/generate", self.api_generate)
+        r.add_post("/api/chat", self.api_chat)
         r.add_post("/v1/completions", self.v1_completions)
         r.add_post("/v1/chat/completions", self.v1_chat)
         r.add_get("/health", self.health)

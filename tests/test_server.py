@@ -111,6 +111,32 @@ def test_stop_strings_cut_the_stream_and_release_the_request():
     assert open_streams == 0
 
 
+def test_ollama_chat_endpoint_streams_message_pieces():
+    """`/api/chat` — the endpoint `langchain_ollama.ChatOllama` of the reference's notebooks talks to
+    (`/root/reference/notebooks/llm_requests.ipynb:53-57`): NDJSON lines with a `message` piece each, a final `done`
+    record with the timing tail; non-streamed form; same tokens as `/api/generate` on the flattened prompt."""
+    async def body(server, base):
+        async with aiohttp.ClientSession() as s:
+            msgs = [{"role": "system", "content": "be brief"}, {"role": "user", "content": "hi"}]
+            p = {"model": "m", "messages": msgs, "options": {"num_predict": 6, "temperature": 0}}
+            lines = []
+            async with s.post(base + "/api/chat", json=p) as r:
+                assert r.status == 200 and r.headers["Content-Type"].startswith("application/x-ndjson")
+                async for raw in r.content:
+                    lines.append(json.loads(raw))
+            whole = await (await s.post(base + "/api/chat", json=dict(p, stream=False))).json()
+            flat = await (await s.post(base + "/api/generate", json={"prompt": "system: be brief\nuser: hi\nassistant: ", "stream": False,
+                                                                     "options": p["options"]})).json()
+            bad = await s.post(base + "/api/chat", json={"messages": "hi"})
+            return lines, whole, flat, bad.status
+    lines, whole, flat, bad = with_server(body)
+    assert len(lines) == 7 and all(l["message"]["role"] == "assistant" and not l["done"] for l in lines[:-1])
+    tail = lines[-1]
+    assert tail["done"] and tail["done_reason"] == "length" and tail["eval_count"] == 6 and "context" not in tail
+    text = "".join(l["message"]["content"] for l in lines)
+    assert whole["message"]["content"] == text == flat["response"] and whole["done"] and bad == 400
+
+
 def test_openai_completions_sse_and_usage_and_chat():
     async def body(server, base):
         async with aiohttp.ClientSession() as s:
