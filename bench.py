@@ -98,6 +98,8 @@ def parse(argv=None):
     ap.add_argument("--no-gemm-tune", action="store_true", help="skip the start-up GEMM dispatch measurement (A/B)")
     ap.add_argument("--no-mixed-graphs", action="store_true", help="capture pure-decode steps only (A/B of the mixed-step graphs)")
     ap.add_argument("--no-custom-ar", action="store_true")
+    ap.add_argument("--quantization", default=None, choices=["fp8"],
+                    help="W8A8 dense projections on the fp8 matrix cores (EngineConfig.quantization); NOT the headline config: the line is marked reduced precision")
     ap.add_argument("--no-ttft-tpot-trade", action="store_true",
                     help="TPOT control as a fixed per-step cap (A/B of SchedulerConfig.ttft_tpot_trade)")
     ap.add_argument("--fcfs", action="store_true", help="plain FCFS admission (default: requests past their TTFT deadline yield)")
@@ -315,7 +317,7 @@ def main():
                                                ep_a2a_min_tokens=0 if args.emulate_tp > 1 else args.ep_a2a_min_tokens),
                        device=args.device, seed=args.seed, use_hip_graphs=on_gpu and not args.no_graphs,
                        async_scheduling=False if args.sync_steps else None, mixed_step_graphs=not args.no_mixed_graphs,
-                       tune_gemms=not args.no_gemm_tune)
+                       tune_gemms=not args.no_gemm_tune, quantization=args.quantization)
     t_load = time.perf_counter()
     eng = LLMEngine(cfg, ctx, dev)
     note(f"model built in {time.perf_counter() - t_load:.1f} s, {eng.runner.kv_cache_tokens} KV tokens; warming up")
@@ -380,6 +382,10 @@ def main():
             line["config"]["parallelism"] = f"tp{args.emulate_tp} rank 0 emulated on 1 GPU" + (f"+ep{args.emulate_tp}" if args.ep > 1 else "")
             line["INVALID_emulation"] = (f"one rank's share of a tp{args.emulate_tp} replica with device copies in place of the "
                                          "collectives: a workload study, not a throughput figure of any configuration")
+        if args.quantization:
+            line["dtype"] = f"bf16 activations / KV, {args.quantization} (e4m3, per-token × per-channel scales) dense projections above 64 rows"
+            line["INVALID_reduced_precision"] = ("--quantization: an optional serving mode, not BASELINE.json's bf16 configuration; "
+                                                 "quality on a trained checkpoint is unpinned here")
         if args.num_layers:
             line["INVALID_reduced_model"] = f"--num-layers {args.num_layers}: rehearsal, not the named architecture"
         print(json.dumps(line), file=result_out, flush=True)

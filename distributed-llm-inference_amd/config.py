@@ -194,6 +194,11 @@ class EngineConfig:
     # and dispatch on the result (ops/gemm_plan.py); off: library above 64 rows, except the gate/up heuristics
     tune_gemms: bool = True
     weights_path: Optional[str] = None      # safetensors dir/file; None → random init
+    # "fp8": W8A8 dense projections — weights quantised once to OCP e4m3 with one scale per output channel, activations per
+    # token on the fly (csrc/kernels/quant.hip), GEMMs on the fp8 matrix cores (hipBLASLt through torch._scaled_mm) for
+    # steps of more than 64 rows; decode-sized steps keep the bf16 weight-streaming kernels (both copies stay resident:
+    # 288 GB).  None: bf16 throughout (the default, and what every headline number is measured with).
+    quantization: Optional[str] = None
     tokenizer_path: Optional[str] = None    # HF tokenizer.json; None → byte-level tokenizer
 
 

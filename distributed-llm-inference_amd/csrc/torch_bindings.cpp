@@ -55,6 +55,19 @@ Tensor silu_and_mul(const Tensor& x) {
   return out;
 }
 
+// Per-row dynamic e4m3 quantisation of GEMM inputs (kernels/quant.hip): (q [rows, K] float8_e4m3fn, scales [rows, 1] fp32).
+// silu: x is [rows, 2·K] = [gate | up]; the quantised row is silu(gate) ⊙ up.
+std::tuple<Tensor, Tensor> quant_rows_fp8(const Tensor& x, bool silu) {
+  check_bf16_rows(x, "x");
+  const int64_t rows = x.size(0), K = silu ? x.size(1) / 2 : x.size(1);
+  TORCH_CHECK(K % 16 == 0 && (!silu || x.size(1) == 2 * K), "quant_rows_fp8: row width must be a multiple of 16");
+  Tensor q = at::empty({rows, K}, x.options().dtype(at::kFloat8_e4m3fn));
+  Tensor scales = at::empty({rows, 1}, x.options().dtype(at::kFloat));
+  dli::launch_quant_rows_fp8(silu, x.data_ptr(), x.stride(0), q.data_ptr(), K, scales.data_ptr<float>(), (int)rows, (int)K,
+                             cur_stream(x));
+  return {q, scales};
+}
+
 // y = x · Wᵀ (+ bias) for decode-sized x (≤ 16 rows): the weight-streaming kernel in kernels/skinny_gemm.hip
 // `out` (optional): write the result there instead of a fresh tensor — the row-parallel layers hand in a view of the custom
 // all-reduce's IPC staging buffer, so the reduction reads the GEMM's output in place.
@@ -559,6 +572,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("rms_norm(Tensor x, Tensor weight, float eps) -> Tensor", &rms_norm);
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
+  m.def("quant_rows_fp8(Tensor x, bool silu=False) -> (Tensor, Tensor)", &quant_rows_fp8);
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None) -> Tensor", &skinny_linear);
   m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None, bool split_tail=False) -> Tensor", &dense_gemm256);
   m.def("ar_staging_tensor(int state, int rows, int cols, Tensor like) -> Tensor", &ar_staging_tensor);

@@ -26,7 +26,7 @@ def torch_dtype(name: str) -> torch.dtype:
 
 
 def build_model(cfg: ModelConfig, ctx: Optional[ParallelContext] = None, device="cpu", dtype: Optional[torch.dtype] = None,
-                seed: int = 0, weights_path: Optional[str] = None):
+                seed: int = 0, weights_path: Optional[str] = None, quantization: Optional[str] = None):
     ctx = ctx or SINGLE
     dtype = dtype or torch_dtype(cfg.dtype)
     device = torch.device(device)
@@ -36,6 +36,10 @@ def build_model(cfg: ModelConfig, ctx: Optional[ParallelContext] = None, device=
             load_safetensors(model, weights_path)
         else:
             init_random(model, seed)
+        if quantization:
+            if quantization != "fp8" or not hasattr(model, "quantize_fp8"):
+                raise ValueError(f"quantization {quantization!r} is not available for {cfg.arch} models (supported: fp8 on llama / mixtral)")
+            model.quantize_fp8()
     return model.eval()
 
 

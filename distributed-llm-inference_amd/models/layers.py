@@ -56,6 +56,12 @@ class Weight(nn.Module):
                 assert s % ctx.tp_size == 0, f"segment {s} not divisible by tp={ctx.tp_size}"
             shape[shard_dim] = sum(s // ctx.tp_size for s in self.segments)
         self.data = nn.Parameter(torch.empty(shape, dtype=dtype, device=device), requires_grad=False)
+        self.q: Optional[torch.Tensor] = None              # e4m3 copy + per-output-channel scales (EngineConfig.quantization)
+        self.q_scale: Optional[torch.Tensor] = None
+
+    def quantize_fp8(self) -> None:
+        assert self.data.dim() == 2
+        self.q, self.q_scale = ops.quant_weight_fp8(self.data)
 
     def shard_of(self, full: torch.Tensor) -> torch.Tensor:
         if self.shard_dim is None or self.ctx.tp_size == 1:
@@ -84,8 +90,11 @@ class ColumnParallelLinear(nn.Module):
         self.weight = Weight((sum(out_segments), in_features), 0, ctx, dtype, device, segments=list(out_segments))
         self.bias = Weight((sum(out_segments),), 0, ctx, dtype, device, segments=list(out_segments)) if bias else None
 
-    def forward(self, x):
-        return ops.linear(x, self.weight.data, None if self.bias is None else self.bias.data)
+    def forward(self, x, xq=None):
+        w = self.weight
+        if w.q is not None and self.bias is None and ops.use_fp8(x):
+            return ops.linear_fp8(x, w.q, w.q_scale, xq=xq)
+        return ops.linear(x, w.data, None if self.bias is None else self.bias.data)
 
 
 class Partial:
@@ -151,29 +160,38 @@ class RowParallelLinear(nn.Module):
         self.weight = Weight((out_features, in_features), 1, ctx, dtype, device)
         self.bias = Weight((out_features,), None, ctx, dtype, device) if bias else None
 
-    def forward(self, x, defer: bool = False):
+    def _mm(self, x, b, out=None, xq=None):
+        """The local GEMM: W8A8 for a quantised layer at more than 64 rows (``xq``: input quantised by the caller)."""
+        w = self.weight
+        if w.q is not None and b is None and ops.use_fp8(x):
+            return ops.linear_fp8(x, w.q, w.q_scale, out=out, xq=xq)
+        return ops.linear(x, w.data, b, out=out)
+
+    def forward(self, x, defer: bool = False, xq=None):
         """``defer`` (sequence-parallel step): return the un-reduced partial sums as a ``Partial`` — written straight into
-        the IPC staging buffer — for the consumer's fused reduce + add + norm."""
+        the IPC staging buffer — for the consumer's fused reduce + add + norm.  ``xq``: ``x`` already quantised to e4m3
+        (``(q, scale)``; only meaningful for a quantised layer)."""
         # the bias must be added once, not tp times: only rank 0 adds it before the reduction
         b = None if (self.bias is None or self.ctx.tp_rank != 0) else self.bias.data
+        fp8 = self.weight.q is not None and b is None and ops.use_fp8(x)
         if defer and self.reduce and self.ctx.sp_step:
             ar = self.ctx.custom_ar
             N = self.weight.data.shape[0]
             out = None if self.ctx.emulated else ar.staging_tensor(x.shape[0], N, x)
-            return Partial("reduce", ops.linear(x, self.weight.data, b, out=out))
-        if (self.reduce and self.OVERLAP_OK and self.ctx.distributed and x.is_cuda and x.dim() == 2
+            return Partial("reduce", self._mm(x, b, out, xq))
+        if (self.reduce and self.OVERLAP_OK and self.ctx.distributed and x.is_cuda and x.dim() == 2 and not fp8
                 and x.shape[0] >= self.OVERLAP_MIN_ROWS and self.overlap_capable()):
             return self._forward_overlapped(x, b)
         ar = self.ctx.custom_ar
         if (self.reduce and self.STAGED_OUTPUT and ar is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16
                 and self.ctx.distributed and ar.fits(x.shape[0] * self.weight.data.shape[0] * 2)):
             # the GEMM writes straight into the IPC staging buffer: the reduction kernel has no copy-in pass left
-            y = ops.linear(x, self.weight.data, b, out=ar.staging_tensor(x.shape[0], self.weight.data.shape[0], x))
+            y = self._mm(x, b, ar.staging_tensor(x.shape[0], self.weight.data.shape[0], x), xq)
             c = self.ctx.comm
             c["ar_custom_calls"] += 1
             c["ar_custom_bytes"] += y.numel() * 2
             return ar.all_reduce(y)
-        y = ops.linear(x, self.weight.data, b)
+        y = self._mm(x, b, None, xq)
         return self.ctx.all_reduce(y) if self.reduce else y
 
     def _library_is_stream_ordered(self) -> bool:

@@ -127,7 +127,12 @@ class SwiGLUMLP(nn.Module):
         self.down = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, ctx, dtype, device)
 
     def forward(self, h):
-        return self.down(ops.linear_swiglu(h, self.gate_up.weight.data), defer=True)
+        w13 = self.gate_up.weight
+        if w13.q is not None and ops.use_fp8(h):
+            # W8A8: gate/up on the fp8 matrix cores, then ONE pass that applies SwiGLU and quantises the down projection's input
+            gu = ops.linear_fp8(h, w13.q, w13.q_scale)
+            return self.down(gu, defer=True, xq=ops.quant_rows_fp8(gu, silu=True))
+        return self.down(ops.linear_swiglu(h, w13.data), defer=True)
 
 
 class MoEBlock(nn.Module):
@@ -303,6 +308,21 @@ class LlamaForCausalLM(nn.Module):
         return self.lm_head(h)
 
     # ---- parameter naming (HF checkpoint names → modules) used by init and the safetensors loader
+    @torch.no_grad()
+    def quantize_fp8(self) -> int:
+        """W8A8 (``EngineConfig.quantization = "fp8"``): an e4m3 copy of every dense projection of the decoder layers (qkv, o,
+        gate/up, down) next to the bf16 one; embedding, LM head, norms, routers and MoE experts stay bf16.  Returns the
+        number of quantised matrices."""
+        n = 0
+        for l in self.layers:
+            ws = [l.attn.qkv.weight, l.attn.o.weight]
+            if isinstance(l.mlp, SwiGLUMLP):
+                ws += [l.mlp.gate_up.weight, l.mlp.down.weight]
+            for w in ws:
+                w.quantize_fp8()
+                n += 1
+        return n
+
     def named_weights(self):
         yield "model.embed_tokens.weight", self.embed.weight, "normal"
         for i, l in enumerate(self.layers):

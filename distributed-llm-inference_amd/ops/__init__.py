@@ -262,6 +262,51 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return torch.nn.functional.linear(x, weight, bias)
 
 
+FP8_MIN_ROWS = int(os.environ.get("DLI_FP8_MIN_ROWS", "65"))      # below: the bf16 weight-streaming kernels are the faster path
+FP8_MAX = 448.0                                                   # largest finite OCP e4m3 value
+
+
+def use_fp8(x: torch.Tensor) -> bool:
+    """Does a step of this size take the W8A8 path of a quantised layer?"""
+    return x.dim() == 2 and x.shape[0] >= FP8_MIN_ROWS and x.dtype == torch.bfloat16
+
+
+def quant_rows_fp8(x: torch.Tensor, silu: bool = False):
+    """Per-row dynamic e4m3 quantisation: ``(q [T, K] float8_e4m3fn, scale [T, 1] fp32)`` with ``x ≈ q · scale``.
+    ``silu``: ``x = [gate | up]`` and the quantised row is ``silu(gate) * up`` (``csrc/kernels/quant.hip``)."""
+    if _gpu_kernel_ok(x) and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0:
+        return hip().quant_rows_fp8(x, silu)
+    xf = x.float()
+    if silu:
+        half = x.shape[1] // 2
+        xf = torch.nn.functional.silu(xf[:, :half]) * xf[:, half:]
+    scale = xf.abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / FP8_MAX
+    return (xf / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn), scale
+
+
+def quant_weight_fp8(w: torch.Tensor):
+    """One scale per output channel: ``(q [N, K] float8_e4m3fn, scale [1, N] fp32)``."""
+    wf = w.float()
+    scale = wf.abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / FP8_MAX
+    return (wf / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).contiguous(), scale.t().contiguous()
+
+
+def linear_fp8(x: Optional[torch.Tensor], wq: torch.Tensor, w_scale: torch.Tensor, out: Optional[torch.Tensor] = None,
+               xq=None) -> torch.Tensor:
+    """``x @ Wᵀ`` with both operands in e4m3 and fp32 accumulation on the fp8 matrix cores; per-token × per-channel scales
+    applied by the GEMM's epilogue (hipBLASLt through ``torch._scaled_mm``), bf16 result.  ``xq``: an already quantised
+    input ``(q, scale)`` (the SwiGLU output comes out of ``quant_rows_fp8(silu=True)`` that way)."""
+    q, xs = xq if xq is not None else quant_rows_fp8(x)
+    if q.is_cuda:
+        y = torch._scaled_mm(q, wq.t(), scale_a=xs, scale_b=w_scale, out_dtype=torch.bfloat16)
+    else:                                                    # reference (CPU tests): the same quantised operands in fp32
+        y = ((q.float() * xs) @ (wq.float() * w_scale.t()).t()).to(torch.bfloat16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 GEMM256_SWIGLU = not os.environ.get("DLI_NO_GEMM256_SWIGLU")
 
 

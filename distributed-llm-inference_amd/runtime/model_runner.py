@@ -59,7 +59,7 @@ class ModelRunner:
         if self.on_gpu and self.dtype != torch.bfloat16:
             self.dtype = torch.bfloat16                      # the HIP kernels are bf16
         t0 = time.perf_counter()
-        self.model = build_model(mcfg, self.ctx, device, self.dtype, cfg.seed, cfg.weights_path)
+        self.model = build_model(mcfg, self.ctx, device, self.dtype, cfg.seed, cfg.weights_path, cfg.quantization)
         self.load_seconds = time.perf_counter() - t0
         self.kv_dtype = torch.float8_e4m3fn if cfg.cache.kv_dtype == "fp8" else self.dtype
         self.local_kv_heads = mcfg.num_kv_heads // self.ctx.tp_size
@@ -864,6 +864,8 @@ class ModelRunner:
             def add(name, w, swiglu):
                 groups.setdefault((name, tuple(w.shape), swiglu), []).append(w)
             for mod in self.model.modules():
+                if self.cfg.quantization:                    # rows above the skinny range run W8A8: nothing to choose
+                    break
                 if isinstance(mod, Attention):
                     add("qkv", mod.qkv.weight.data, False)
                     add("o", mod.o.weight.data, False)

@@ -344,6 +344,40 @@ def test_ttft_tpot_trade_spends_saved_step_time_on_urgent_prompts_only():
     assert b.burst_grant == 0 and b.total_tokens == 256
 
 
+@pytest.mark.parametrize("model", ["tiny-llama", "tiny-mixtral"])
+def test_fp8_w8a8_projections_track_the_bf16_model(model):
+    """`EngineConfig.quantization = "fp8"`: an e4m3 copy of every dense projection (per-output-channel scales), activations
+    quantised per token, used by steps of ≥ 65 rows — here through the fp32 reference of the same quantised operands
+    (the GPU path runs them on the fp8 matrix cores: tests/test_kernels_gpu.py, test_engine_gpu.py).  The final hidden
+    states of an 80-token prefill must track the bf16 model; a decode-sized step does not touch the fp8 copies."""
+    from dli_amd.models import build_model
+    from dli_amd.models.layers import Weight
+    cfg = get_model_config(model)
+    plain = build_model(cfg, None, "cpu", torch.bfloat16, 3)
+    quant = build_model(cfg, None, "cpu", torch.bfloat16, 3, None, "fp8")
+    qw = [m for m in quant.modules() if isinstance(m, Weight) and m.q is not None]
+    assert len(qw) == cfg.num_layers * (2 if cfg.num_experts else 4) and not any(m.q is not None for m in plain.modules() if isinstance(m, Weight))
+    w = qw[0]
+    assert w.q.dtype == torch.float8_e4m3fn and w.q_scale.shape == (1, w.data.shape[0])
+    deq = w.q.float() * w.q_scale.t()
+    assert (deq - w.data.float()).abs().max() <= 0.07 * w.data.float().abs().max()      # e4m3: 3 mantissa bits
+
+    def hidden(m, L):
+        nb = (L + 31) // 32
+        caches = ops.allocate_kv_cache(cfg.num_layers, nb, cfg.num_kv_heads, cfg.head_dim, torch.bfloat16, "cpu")
+        meta = ops.AttnMetadata(num_decode=0, num_prefill=1, num_tokens=L, positions=torch.arange(L, dtype=torch.int32),
+                                slot_mapping=torch.arange(L, dtype=torch.int32), block_tables=torch.arange(nb, dtype=torch.int32)[None],
+                                seq_lens=torch.tensor([L], dtype=torch.int32), query_start_loc=torch.tensor([0, L], dtype=torch.int32))
+        with torch.inference_mode():
+            return m(torch.arange(5, 5 + L), meta, caches).float()
+    a, b = hidden(plain, 80), hidden(quant, 80)
+    cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
+    assert 0.99 < cos < 1.0, cos                              # close, and not the same numbers: the fp8 path did run
+    assert torch.equal(hidden(plain, 12), hidden(quant, 12))  # 12 rows < FP8_MIN_ROWS: the bf16 weights serve the step
+    with pytest.raises(ValueError):
+        build_model(get_model_config("tiny-opt"), None, "cpu", torch.bfloat16, 3, None, "fp8")
+
+
 def test_decode_sized_gemm_dispatch_rule():
     """ops.linear: which (rows, N, K) go to the weight-streaming kernel (csrc/kernels/skinny_gemm.hip)."""
     from dli_amd import ops

@@ -236,3 +236,38 @@ def test_pipelined_stepping_on_gpu_is_bit_identical(graphs):
     if graphs:
         assert eng.runner.stats["graph_steps"] > 20
     assert eng.bm.num_free == eng.bm.num_blocks
+
+
+def test_fp8_w8a8_engine_on_gpu_tracks_the_bf16_engine(tmp_path):
+    """`quantization="fp8"` end to end on the GPU: prefill and mixed steps of ≥ 65 rows run the dense projections on the fp8
+    matrix cores (captured in the mixed-step hipGraphs, graph-vs-eager self-test included), decode-sized steps stay on the
+    bf16 weight-streaming kernels.  First-step logits track the bf16 engine; greedy tokens mostly agree (random-init
+    weights: near-uniform logits, so token agreement is a loose bound — parity on a trained checkpoint is unpinned here)."""
+    import dli_amd.runtime.model_runner as mr
+    from dli_amd.config import CacheConfig, EngineConfig, SamplingParams, SchedulerConfig, get_model_config
+    from dli_amd.engine.engine import LLMEngine
+    rng = np.random.default_rng(9)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (300, 90, 150)]
+    outs, logits = {}, {}
+    for name, quant in (("bf16", None), ("fp8", "fp8")):
+        f = str(tmp_path / f"logits_{name}.pt")
+        mr._DUMP_LOGITS = f                                   # (read from DLI_DUMP_LOGITS at import time)
+        try:
+            cfg = EngineConfig(model=get_model_config("tiny-llama-tp"), cache=CacheConfig(num_blocks=256),
+                               sched=SchedulerConfig(max_num_seqs=8, max_num_batched_tokens=1024, max_model_len=1024,
+                                                     long_prefill_chunk=1024),
+                               device="cuda", graph_batch_sizes=(4, 8), quantization=quant)
+            eng = LLMEngine(cfg)
+            eng.warmup()
+            outs[name] = eng.generate(None, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True), prompt_ids=prompts)
+            st = eng.runner.selftest
+            assert st["graph_vs_eager"]["ok"] and st["mixed_graph_vs_eager"]["ok"], st
+            assert eng.runner.stats["mixed_graph_steps"] > 0
+            eng.shutdown()
+        finally:
+            mr._DUMP_LOGITS = ""
+        logits[name] = torch.load(f, weights_only=True)
+    cos = torch.nn.functional.cosine_similarity(logits["bf16"].flatten().float(), logits["fp8"].flatten().float(), dim=0).item()
+    assert 0.99 < cos < 1.0, cos
+    first = np.mean([a[0] == b[0] for a, b in zip(outs["bf16"], outs["fp8"])])
+    assert first >= 2 / 3, (outs, first)

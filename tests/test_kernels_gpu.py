@@ -443,6 +443,47 @@ def test_dense_gemm256_split_tail_matches_fp32_reference_and_the_plain_tiles(M, 
         assert (got == plain).float().mean() > 0.5
 
 
+@pytest.mark.parametrize("M,K,silu", [(70, 4096, False), (300, 14336, False), (5, 256, False), (129, 14336, True), (33, 28672, False),
+                                       (64, 3584, True)])
+def test_quant_rows_fp8_matches_reference(M, K, silu):
+    """csrc/kernels/quant.hip: per-row scale = amax / 448, values = e4m3(x / scale) — against the torch composite on the same
+    input (scales to fp32 rounding, codes equal except where x / scale sits on a rounding boundary); rows longer than the
+    register-resident 16384 and the fused SwiGLU form included."""
+    x = _bf(M, (2 if silu else 1) * K, seed=81, scale=2.0)
+    x[0] = 0                                                  # an all-zero row must not produce NaN / inf
+    q, s = ops.hip().quant_rows_fp8(x, silu)
+    assert q.dtype == torch.float8_e4m3fn and q.shape == (M, K) and s.shape == (M, 1) and s.dtype == torch.float32
+    xf = x.float()
+    if silu:
+        xf = torch.nn.functional.silu(xf[:, :K]) * xf[:, K:]
+    want_s = xf.abs().amax(dim=1, keepdim=True).clamp_min(1e-12) / 448.0
+    assert torch.allclose(s[1:], want_s[1:], rtol=2e-2 if silu else 1e-6)            # silu: fast exp2 / rcp in the kernel
+    deq = q.float() * s
+    assert torch.isfinite(deq).all() and (deq[0] == 0).all()
+    err = (deq - xf).abs() / xf.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
+    assert err.max() < 0.04, err.max()                        # half an e4m3 step at the top of the range is 1/32 of amax
+    if not silu:
+        want_q = (xf / want_s).clamp(-448, 448).to(torch.float8_e4m3fn)
+        assert (q.view(torch.uint8) == want_q.view(torch.uint8)).float().mean() > 0.999
+
+
+@pytest.mark.parametrize("M,N,K", [(2304, 6144, 4096), (70, 4096, 14336), (300, 28672, 4096)])
+def test_linear_fp8_tracks_fp32_reference(M, N, K):
+    """W8A8 GEMM (per-token × per-channel scales, fp8 matrix cores through torch._scaled_mm) against the fp32 product of the
+    bf16 operands, and against the fp32 product of the SAME quantised operands (that one tightly: the GEMM itself is exact
+    up to accumulation order)."""
+    x = _bf(M, K, seed=83)
+    w = _bf(N, K, seed=84, scale=0.05)
+    wq, ws = ops.quant_weight_fp8(w)
+    got = ops.linear_fp8(x, wq, ws).float()
+    ref = x.float() @ w.float().t()
+    assert got.shape == (M, N) and torch.isfinite(got).all()
+    assert torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item() > 0.998
+    q, s = ops.quant_rows_fp8(x)
+    same = (q.float() * s) @ (wq.float() * ws.t()).t()
+    assert (got - same).abs().max() / same.abs().max() < 1e-2
+
+
 def test_dense_gemm256_identity_check_with_asymmetric_weights():
     """A = I with an asymmetric W: catches a transposed or permuted C write that symmetric data would hide."""
     K = N = 256
