@@ -149,6 +149,27 @@ def test_tp2_real_shapes_logits_track_tp1(model, ep, a2a, tmp_path):
     assert cos > 0.9995, cos
 
 
+def test_tp2_w8a8_tracks_tp1_w8a8_and_bf16(tmp_path):
+    """`quantization="fp8"` under tensor parallelism: every rank quantises its own shards (column-parallel: the same
+    per-channel scales as the unsharded matrix; row-parallel: scales over the rank's K slice, activations quantised per
+    token over that slice), partial sums reduced in bf16 as before — incl. the sequence-parallel reduce + add + norm and the
+    IPC staging buffer as the GEMM's destination.  First-step logits of TP = 2 track TP = 1 (both W8A8) and bf16 TP = 2."""
+    rng = np.random.default_rng(12)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (700, 333, 90)]
+    logits = {}
+    for name, tp, env in (("q1", 1, {"DLI_TEST_QUANT": "fp8"}), ("q2", 2, {"DLI_TEST_QUANT": "fp8", "DLI_SP_FORCE": "1", "DLI_SP_MIN_BYTES": "65536"}),
+                          ("b2", 2, {})):
+        f = str(tmp_path / f"logits_{name}.pt")
+        out = run("tiny-llama-tp", tp, 1, prompts, dict(env, DLI_DUMP_LOGITS=f, DLI_OVERLAP_MIN_ROWS="1000000"))
+        assert out["mixed_graph_steps"] > 0
+        if name == "q2":
+            assert out["sp_norm_calls"] > 0
+        logits[name] = torch.load(f, weights_only=True)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(logits[a], logits[b], dim=0).item()
+    assert cos("q1", "q2") > 0.995, cos("q1", "q2")
+    assert 0.99 < cos("q2", "b2") < 1.0, cos("q2", "b2")
+
+
 def _replay_http(tmp_path, extra):
     import socket
     root = os.path.dirname(HERE)

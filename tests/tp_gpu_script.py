@@ -22,7 +22,7 @@ def main():
                        parallel=ParallelConfig(tp=tp, ep=ep, backend=backend,
                                                ep_a2a_min_tokens=int(os.environ.get("DLI_TEST_EP_A2A", "2048")),
                                                custom_all_reduce=os.environ.get("DLI_NO_CUSTOM_AR") != "1"), device="cuda",
-                       graph_batch_sizes=(4, 8),
+                       graph_batch_sizes=(4, 8), quantization=os.environ.get("DLI_TEST_QUANT") or None,
                        async_scheduling={"0": False, "1": True}.get(os.environ.get("DLI_TEST_ASYNC", ""), None))
     ctx = maybe_launch_tp(cfg)
     eng = LLMEngine(cfg, ctx)
