@@ -298,6 +298,8 @@ def linear_fp8(x: Optional[torch.Tensor], wq: torch.Tensor, w_scale: torch.Tenso
     input ``(q, scale)`` (the SwiGLU output comes out of ``quant_rows_fp8(silu=True)`` that way)."""
     q, xs = xq if xq is not None else quant_rows_fp8(x)
     if q.is_cuda:
+        if out is not None and out.is_contiguous():          # e.g. the all-reduce's IPC staging buffer: no copy pass
+            return torch._scaled_mm(q, wq.t(), scale_a=xs, scale_b=w_scale, out_dtype=torch.bfloat16, out=out)
         y = torch._scaled_mm(q, wq.t(), scale_a=xs, scale_b=w_scale, out_dtype=torch.bfloat16)
     else:                                                    # reference (CPU tests): the same quantised operands in fp32
         y = ((q.float() * xs) @ (wq.float() * w_scale.t()).t()).to(torch.bfloat16)
