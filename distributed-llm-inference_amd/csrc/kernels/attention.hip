@@ -32,15 +32,6 @@ constexpr int HD = 128;                 // head dim
 constexpr int PAGE_ELEMS = HD * 32;     // elements per (page, kv head)
 constexpr float NEG_BIG = -1.0e30f;
 
-// 4 packed e4m3 bytes → 4 bf16 (elements 4i..4i+3 of a fragment)
-__device__ __forceinline__ void fp8x4_to_bf16(uint32_t w, bf16x8& f, int base) {
-  const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
-  const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
-  f[base + 0] = (short)f2bf(lo[0]);
-  f[base + 1] = (short)f2bf(lo[1]);
-  f[base + 2] = (short)f2bf(hi[0]);
-  f[base + 3] = (short)f2bf(hi[1]);
-}
 
 // ---- fragment loads ------------------------------------------------------------------------------
 // K fragment for row tile rt (tokens 16rt..16rt+15) and k-step c (0..3) of lane (col, g).

@@ -57,6 +57,16 @@ __device__ __forceinline__ uint8_t f_to_fp8(float f) {
   return static_cast<uint8_t>(packed & 0xff);
 }
 
+// 4 packed e4m3 bytes → 4 bf16 (elements base..base+3 of a fragment; exact: e4m3 fits bf16)
+__device__ __forceinline__ void fp8x4_to_bf16(uint32_t w, bf16x8& f, int base) {
+  const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, false);
+  const f32x2 hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)w, true);
+  f[base + 0] = (short)f2bf(lo[0]);
+  f[base + 1] = (short)f2bf(lo[1]);
+  f[base + 2] = (short)f2bf(hi[0]);
+  f[base + 3] = (short)f2bf(hi[1]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -35,7 +35,7 @@ void launch_paged_prefill(const void* q, int64_t q_stride, const void* k_cache, 
                           const int* counts, hipStream_t stream);
 
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
-                          int M, int N, int K, bool swiglu, hipStream_t stream);
+                          int M, int N, int K, bool swiglu, const float* w_scale, hipStream_t stream);
 void launch_moe_skinny(bool down, const void* a, int64_t a_stride, const void* w, int64_t w_expert_stride,
                        const int* sorted_ids, const int* tile_expert, const int* meta, const float* topk_w, int top_k,
                        void* out, int64_t out_stride, int K, int N, int max_tiles, int max_rows, hipStream_t stream);

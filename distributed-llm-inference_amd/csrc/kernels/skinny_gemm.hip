@@ -51,9 +51,15 @@ __device__ __forceinline__ int x_swz(int t) { return XI == 4 ? t : XI == 2 ? (t 
 // The streaming loop + cross-wave reduction, shared by the dense and the MoE kernels.  xsrc[i] / wsrc[i]: this
 // lane's source of DMA instruction i (tile row 4i + (lane>>4), swizzled chunk already added) at k = 0.
 // Returns to thread t the sum for token m = t>>4 and weight row (t&15) of the tile.
-template <int XI, int NW = SK_WAVES, int WAUX = SK_AUX_KEEP>
-__device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const char* const (&wsrc)[4], int K, char* smem) {
-  constexpr int SLOT = XI * 1024 + SK_TILE;           // bytes per slab: activations + weight tile
+// W8: the weights are OCP e4m3 (W8A16 decode of the fp8 option): a weight tile row is 128 bytes, the tile 2 KiB = 2 DMA
+// instructions (8 rows × 128 B each: lane → row lane/8, 16-byte chunk lane%8, swizzled by the row like the bf16 tile);
+// a lane's fragment of k-block j is 8 bytes, widened to bf16 in registers (exact) for the same bf16 MFMA — half the
+// weight bytes per output, and weights are all this kernel streams.  The per-channel scale is the caller's epilogue.
+template <int XI, int NW = SK_WAVES, int WAUX = SK_AUX_KEEP, bool W8 = false>
+__device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const char* const (&wsrc)[W8 ? 2 : 4], int K, char* smem) {
+  constexpr int WT = W8 ? SK_TILE / 2 : SK_TILE;     // bytes of a weight tile
+  constexpr int WI = W8 ? 2 : 4;                      // DMA instructions per weight tile
+  constexpr int SLOT = XI * 1024 + WT;                // bytes per slab: activations + weight tile
   constexpr int XROWS = 4 * XI;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
@@ -66,8 +72,8 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
     const int64_t kb_ = (int64_t)(slab_) * 256;                                                                    \
     _Pragma("unroll") for (int i = 0; i < XI; ++i)                                                                 \
         __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[i] + kb_), (lptr_t)(dst_ + i * 1024), 16, 0, 0);            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                  \
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kb_), (lptr_t)(dst_ + (XI + i) * 1024), 16, 0, WAUX);     \
+    _Pragma("unroll") for (int i = 0; i < WI; ++i)                                                                 \
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + (W8 ? kb_ / 2 : kb_)), (lptr_t)(dst_ + (XI + i) * 1024), 16, 0, WAUX); \
   }
 
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -76,7 +82,8 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
   const int xr = r & (XROWS - 1);                      // columns ≥ XROWS alias loaded rows (never stored)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    frag_off[j] = XI * 1024 + r * 256 + (((4 * j + g) ^ r) << 4);
+    if (W8) frag_off[j] = XI * 1024 + r * 128 + ((((4 * j + g) >> 1) ^ (r & 7)) << 4) + ((4 * j + g) & 1) * 8;
+    else frag_off[j] = XI * 1024 + r * 256 + (((4 * j + g) ^ r) << 4);
     xfrag_off[j] = xr * 256 + (((4 * j + g) ^ x_swz<XI>(xr)) << 4);
   }
 
@@ -86,7 +93,7 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
     // the other slot was consumed by the MFMAs of the previous iteration (they waited for its ds_reads)
     if (it + NW < n_it) {
       DLI_SK_ISSUE(it + NW, slot ^ 1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + 4) : "memory");     // everything but the slab just issued
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XI + WI) : "memory");    // everything but the slab just issued
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -94,7 +101,14 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bf16x8 xf = *reinterpret_cast<const bf16x8*>(base + xfrag_off[j]);
-      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(base + frag_off[j]);
+      bf16x8 wf;
+      if (W8) {
+        const u32x2 raw = *reinterpret_cast<const u32x2*>(base + frag_off[j]);
+        fp8x4_to_bf16(raw[0], wf, 0);
+        fp8x4_to_bf16(raw[1], wf, 4);
+      } else {
+        wf = *reinterpret_cast<const bf16x8*>(base + frag_off[j]);
+      }
       acc = mfma16(wf, xf, acc);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragments are in registers before the slot is refilled
@@ -121,12 +135,12 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
 // SWIGLU: W is a fused [gate; up] projection (N = 2·I rows).  A workgroup then takes 8 gate rows and the 8 matching
 // up rows as its 16-row tile and stores silu(gate)·up — [M, I] — so the activation kernel and the round trip of the
 // [M, 2·I] intermediate disappear from the decode step.
-template <int XI, bool SWIGLU, int NW>
+template <int XI, bool SWIGLU, int NW, bool W8 = false>
 __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* __restrict__ x, int64_t x_stride,
-                                                                      const uint16_t* __restrict__ w,
+                                                                      const void* __restrict__ w_,
                                                                       const uint16_t* __restrict__ bias,
                                                                       uint16_t* __restrict__ out, int64_t out_stride,
-                                                                      int M, int N, int K) {
+                                                                      int M, int N, int K, const float* __restrict__ w_scale) {
   extern __shared__ __attribute__((aligned(1024))) char sk_smem[];
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
   // XCD x streams the x-th eighth of the weight rows: neighbouring 16-column pieces of an output row (32 bytes each)
@@ -137,12 +151,13 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* 
   const int n0 = wg * (SWIGLU ? 8 : 16);
   // DMA sources: instruction i of a tile covers tile rows 4i + (lane>>4); this lane supplies LDS chunk p = lane&15,
   // i.e. global chunk p ^ row.  Rows ≥ M repeat the last token.
-  const char* wsrc[4];
+  const char* wsrc[W8 ? 2 : 4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = 4 * i + g;
+  for (int i = 0; i < (W8 ? 2 : 4); ++i) {
+    const int row = W8 ? 8 * i + (lane >> 3) : 4 * i + g;
     const int wrow = SWIGLU ? (row < 8 ? n0 + row : (N >> 1) + n0 + row - 8) : n0 + row;
-    wsrc[i] = reinterpret_cast<const char*>(w + (int64_t)wrow * K) + ((r ^ row) << 4);
+    if (W8) wsrc[i] = reinterpret_cast<const char*>(w_) + (int64_t)wrow * K + (((lane & 7) ^ (row & 7)) << 4);
+    else wsrc[i] = reinterpret_cast<const char*>(reinterpret_cast<const uint16_t*>(w_) + (int64_t)wrow * K) + ((r ^ row) << 4);
   }
   // More than 16 tokens: further passes over the same 16 weight rows, 16 tokens each.  The workgroup re-reads the
   // 32–112 KiB it has just streamed; with K ≤ 1024-sized shards those re-reads hit L2 and the pass costs ≈ 40 % of
@@ -156,9 +171,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* 
       xsrc[i] = reinterpret_cast<const char*>(x + (int64_t)(m0 + min(row, Ms - 1)) * x_stride) + ((r ^ x_swz<XI>(row)) << 4);
     }
     float s;
-    if (XI < 4 || m0 + 16 >= M) s = skinny_dot<XI, NW, SK_AUX_NT>(xsrc, wsrc, K, sk_smem);     // the last (or only) pass
-    else s = skinny_dot<XI, NW, SK_AUX_KEEP>(xsrc, wsrc, K, sk_smem);
+    if (XI < 4 || m0 + 16 >= M) s = skinny_dot<XI, NW, SK_AUX_NT, W8>(xsrc, wsrc, K, sk_smem);     // the last (or only) pass
+    else s = skinny_dot<XI, NW, SK_AUX_KEEP, W8>(xsrc, wsrc, K, sk_smem);
     const int m = threadIdx.x >> 4, nn = threadIdx.x & 15;   // m ≥ 16 (waves 4–7 of the 8-wave form): nothing to store
+    if (W8) s *= w_scale[SWIGLU ? (nn < 8 ? n0 + nn : (N >> 1) + n0 + nn - 8) : n0 + nn];     // per-output-channel scale
     if (SWIGLU) {
       const float up = __shfl_xor(s, 8, 64);           // thread nn < 8 holds gate column n0 + nn, thread nn + 8 its up
       if (m < Ms && nn < 8)
@@ -233,39 +249,48 @@ __global__ __launch_bounds__(NW * 64) void moe_skinny_kernel(const uint16_t* __r
 // do not cost occupancy.  Measured in a hipGraph: −4…−14 % up to 256 workgroups (one per CU either way) at any M, and
 // −4…−6 % on every shape at M ≤ 4 (80 KiB: still two workgroups per CU; gate/up 6.0, LM head 6.3 TB/s); with M > 4
 // and more workgroups than CUs the lost occupancy costs more than the shorter chain gains.
-template <int XI, bool SWIGLU, int NW>
+template <int XI, bool SWIGLU, int NW, bool W8>
 static void launch_skinny(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
-                          int M, int N, int K, hipStream_t stream) {
-  constexpr int lds = NW * 2 * (XI * 1024 + SK_TILE);
-  hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU, NW>), dim3((N / 16 + 7) / 8 * 8), dim3(NW * 64), lds, stream, (const uint16_t*)x,
-                     x_stride, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out, out_stride, M, N, K);
+                          int M, int N, int K, const float* w_scale, hipStream_t stream) {
+  constexpr int lds = NW * 2 * (XI * 1024 + (W8 ? SK_TILE / 2 : SK_TILE));
+  hipLaunchKernelGGL((skinny_linear_kernel<XI, SWIGLU, NW, W8>), dim3((N / 16 + 7) / 8 * 8), dim3(NW * 64), lds, stream,
+                     (const uint16_t*)x, x_stride, w, (const uint16_t*)bias, (uint16_t*)out, out_stride, M, N, K, w_scale);
 }
 
-template <int XI>
+template <int XI, bool W8>
 static void allow_big_lds() {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, false, 8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * (XI * 1024 + SK_TILE));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, true, 8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * (XI * 1024 + SK_TILE));
+  constexpr int lds = 8 * 2 * (XI * 1024 + (W8 ? SK_TILE / 2 : SK_TILE));
+  if (lds <= 65536) return;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, false, 8, W8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_linear_kernel<XI, true, 8, W8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
+// w_scale != nullptr: `w` is OCP e4m3 [N, K] with one fp32 scale per output channel (W8A16).
 void launch_skinny_linear(void* out, int64_t out_stride, const void* x, int64_t x_stride, const void* w, const void* bias,
-                          int M, int N, int K, bool swiglu, hipStream_t stream) {
+                          int M, int N, int K, bool swiglu, const float* w_scale, hipStream_t stream) {
   // > 64 KiB of dynamic LDS needs an opt-in per kernel; done for every 8-wave variant on the first call, so that no
   // attribute call can fall inside a later stream capture
-  static const bool configured = [] { allow_big_lds<1>(); allow_big_lds<2>(); allow_big_lds<4>(); return true; }();
+  static const bool configured = [] {
+    allow_big_lds<1, false>(); allow_big_lds<2, false>(); allow_big_lds<4, false>();
+    allow_big_lds<1, true>(); allow_big_lds<2, true>(); allow_big_lds<4, true>();
+    return true;
+  }();
   (void)configured;
   const int tiles = N / 16;
   const bool narrow = (tiles <= 256 || M <= 4) && K >= 1024 && !g_skinny_no_8w;
-#define DLI_SK(XI_)                                                                                   \
-  (swiglu ? (narrow ? launch_skinny<XI_, true, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)    \
-                    : launch_skinny<XI_, true, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream))   \
-          : (narrow ? launch_skinny<XI_, false, 8>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)   \
-                    : launch_skinny<XI_, false, 4>(out, out_stride, x, x_stride, w, bias, M, N, K, stream)))
+#define DLI_SK2(XI_, W8_)                                                                                             \
+  (swiglu ? (narrow ? launch_skinny<XI_, true, 8, W8_>(out, out_stride, x, x_stride, w, bias, M, N, K, w_scale, stream)    \
+                    : launch_skinny<XI_, true, 4, W8_>(out, out_stride, x, x_stride, w, bias, M, N, K, w_scale, stream))   \
+          : (narrow ? launch_skinny<XI_, false, 8, W8_>(out, out_stride, x, x_stride, w, bias, M, N, K, w_scale, stream)   \
+                    : launch_skinny<XI_, false, 4, W8_>(out, out_stride, x, x_stride, w, bias, M, N, K, w_scale, stream)))
+#define DLI_SK(XI_) (w_scale != nullptr ? DLI_SK2(XI_, true) : DLI_SK2(XI_, false))
   if (M <= 4) DLI_SK(1);
   else if (M <= 8) DLI_SK(2);
   else DLI_SK(4);
 #undef DLI_SK
+#undef DLI_SK2
 }
 
 template <int XI, bool DOWN, int NW>

@@ -78,13 +78,21 @@ Tensor take_out(const c10::optional<Tensor>& out, int64_t M, int64_t N, const Te
   return *out;
 }
 
+// w_scale given: `w` is float8_e4m3fn with one fp32 scale per output channel ([1, N] or [N]) — W8A16 decode of the fp8 option.
 Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tensor>& bias, bool swiglu,
-                     const c10::optional<Tensor>& out_) {
+                     const c10::optional<Tensor>& out_, const c10::optional<Tensor>& w_scale) {
   check_bf16_rows(x, "x");
   const int64_t M = x.size(0), K = x.size(1), N = w.size(0);
   TORCH_CHECK(M >= 1 && M <= 64, "skinny_linear: 1..64 rows, got ", M);
-  TORCH_CHECK(w.is_cuda() && w.scalar_type() == at::kBFloat16 && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
-              "skinny_linear: weight must be a contiguous bf16 [N, K] GPU tensor with K = ", K);
+  const float* ws = nullptr;
+  if (w_scale.has_value()) {
+    TORCH_CHECK(w.scalar_type() == at::kFloat8_e4m3fn, "skinny_linear: a weight scale goes with float8_e4m3fn weights");
+    TORCH_CHECK(w_scale->is_cuda() && w_scale->scalar_type() == at::kFloat && w_scale->is_contiguous() && w_scale->numel() == N,
+                "skinny_linear: w_scale must be a contiguous fp32 GPU tensor with one entry per output channel");
+    ws = w_scale->data_ptr<float>();
+  }
+  TORCH_CHECK(w.is_cuda() && (ws != nullptr || w.scalar_type() == at::kBFloat16) && w.dim() == 2 && w.is_contiguous() && w.size(1) == K,
+              "skinny_linear: weight must be a contiguous bf16 (or, with w_scale, float8_e4m3fn) [N, K] GPU tensor with K = ", K);
   TORCH_CHECK(K % 128 == 0 && N % 16 == 0 && reinterpret_cast<uintptr_t>(w.data_ptr()) % 16 == 0,
               "skinny_linear: K % 128 == 0 and N % 16 == 0 required, got N=", N, " K=", K);
   const void* b = nullptr;
@@ -97,7 +105,7 @@ Tensor skinny_linear(const Tensor& x, const Tensor& w, const c10::optional<Tenso
   const int64_t n_out = swiglu ? N / 2 : N;
   Tensor out = take_out(out_, M, n_out, x);
   dli::launch_skinny_linear(out.data_ptr(), n_out, x.data_ptr(), x.stride(0), w.data_ptr(), b, (int)M, (int)N, (int)K, swiglu,
-                            cur_stream(x));
+                            ws, cur_stream(x));
   return out;
 }
 
@@ -573,7 +581,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
   m.def("quant_rows_fp8(Tensor x, bool silu=False) -> (Tensor, Tensor)", &quant_rows_fp8);
-  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None) -> Tensor", &skinny_linear);
+  m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None, Tensor? w_scale=None) -> Tensor", &skinny_linear);
   m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None, bool split_tail=False) -> Tensor", &dense_gemm256);
   m.def("ar_staging_tensor(int state, int rows, int cols, Tensor like) -> Tensor", &ar_staging_tensor);
   m.def("ar_all_reduce_add_norm(int state, Tensor staged, Tensor(a!) residual, Tensor weight, float eps, Tensor(b!) out, int blocks=0) -> ()",

@@ -92,8 +92,11 @@ class ColumnParallelLinear(nn.Module):
 
     def forward(self, x, xq=None):
         w = self.weight
-        if w.q is not None and self.bias is None and ops.use_fp8(x):
-            return ops.linear_fp8(x, w.q, w.q_scale, xq=xq)
+        if w.q is not None and self.bias is None:
+            if ops.use_fp8(x):
+                return ops.linear_fp8(x, w.q, w.q_scale, xq=xq)
+            if ops.skinny_w8_ok(x, w.q):
+                return ops.linear_w8(x, w.q, w.q_scale)
         return ops.linear(x, w.data, None if self.bias is None else self.bias.data)
 
 
@@ -163,8 +166,11 @@ class RowParallelLinear(nn.Module):
     def _mm(self, x, b, out=None, xq=None):
         """The local GEMM: W8A8 for a quantised layer at more than 64 rows (``xq``: input quantised by the caller)."""
         w = self.weight
-        if w.q is not None and b is None and ops.use_fp8(x):
-            return ops.linear_fp8(x, w.q, w.q_scale, out=out, xq=xq)
+        if w.q is not None and b is None:
+            if ops.use_fp8(x):
+                return ops.linear_fp8(x, w.q, w.q_scale, out=out, xq=xq)
+            if ops.skinny_w8_ok(x, w.q):
+                return ops.linear_w8(x, w.q, w.q_scale, out=out)
         return ops.linear(x, w.data, b, out=out)
 
     def forward(self, x, defer: bool = False, xq=None):

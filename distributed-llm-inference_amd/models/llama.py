@@ -132,6 +132,8 @@ class SwiGLUMLP(nn.Module):
             # W8A8: gate/up on the fp8 matrix cores, then ONE pass that applies SwiGLU and quantises the down projection's input
             gu = ops.linear_fp8(h, w13.q, w13.q_scale)
             return self.down(gu, defer=True, xq=ops.quant_rows_fp8(gu, silu=True))
+        if w13.q is not None and ops.skinny_w8_ok(h, w13.q, 32):
+            return self.down(ops.linear_w8(h, w13.q, w13.q_scale, swiglu=True), defer=True)     # decode: e4m3 weight stream
         return self.down(ops.linear_swiglu(h, w13.data), defer=True)
 
 

@@ -238,6 +238,20 @@ def _skinny_ok(x: torch.Tensor, weight: torch.Tensor, row_multiple: int) -> bool
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
 
 
+def skinny_w8_ok(x: torch.Tensor, wq: torch.Tensor, row_multiple: int = 16) -> bool:
+    """Decode-sized step of a quantised layer: the weight-streaming kernel reads the e4m3 copy (W8A16, half the bytes).
+    One pass only (≤ 16 rows): 17 rows and more go to the W8A8 GEMM."""
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and wq.dtype == torch.float8_e4m3fn and wq.is_contiguous()
+            and 0 < x.shape[0] <= SKINNY_MAX_ROWS and wq.shape[1] % 128 == 0 and wq.shape[0] % row_multiple == 0
+            and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0)
+
+
+def linear_w8(x: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, swiglu: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ (wq · scale)ᵀ`` for ≤ 16 rows with the weights streamed as e4m3 (``skinny_linear_kernel<…, W8>``)."""
+    return hip().skinny_linear(x, wq, None, swiglu, out, w_scale)
+
+
 def _tile_operand_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.is_contiguous()
             and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0
@@ -262,12 +276,13 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return torch.nn.functional.linear(x, weight, bias)
 
 
-FP8_MIN_ROWS = int(os.environ.get("DLI_FP8_MIN_ROWS", "65"))      # below: the bf16 weight-streaming kernels are the faster path
+FP8_MIN_ROWS = int(os.environ.get("DLI_FP8_MIN_ROWS", "17"))      # below: the weight-streaming kernel (e4m3 weights, bf16 activations)
 FP8_MAX = 448.0                                                   # largest finite OCP e4m3 value
 
 
 def use_fp8(x: torch.Tensor) -> bool:
-    """Does a step of this size take the W8A8 path of a quantised layer?"""
+    """Does a step of this size take the W8A8 GEMM of a quantised layer?  (On the GPU, smaller steps stream the e4m3 weights
+    through the decode kernel — ``skinny_w8_ok`` — and keep their activations in bf16.)"""
     return x.dim() == 2 and x.shape[0] >= FP8_MIN_ROWS and x.dtype == torch.bfloat16
 
 

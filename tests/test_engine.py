@@ -347,7 +347,8 @@ def test_ttft_tpot_trade_spends_saved_step_time_on_urgent_prompts_only():
 @pytest.mark.parametrize("model", ["tiny-llama", "tiny-mixtral"])
 def test_fp8_w8a8_projections_track_the_bf16_model(model):
     """`EngineConfig.quantization = "fp8"`: an e4m3 copy of every dense projection (per-output-channel scales), activations
-    quantised per token, used by steps of ≥ 65 rows — here through the fp32 reference of the same quantised operands
+    quantised per token, used by steps of ≥ 17 rows (smaller steps: the GPU streams the e4m3 weights through the decode
+    kernel, the CPU keeps the bf16 weights) — here through the fp32 reference of the same quantised operands
     (the GPU path runs them on the fp8 matrix cores: tests/test_kernels_gpu.py, test_engine_gpu.py).  The final hidden
     states of an 80-token prefill must track the bf16 model; a decode-sized step does not touch the fp8 copies."""
     from dli_amd.models import build_model

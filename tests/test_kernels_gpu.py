@@ -467,6 +467,24 @@ def test_quant_rows_fp8_matches_reference(M, K, silu):
         assert (q.view(torch.uint8) == want_q.view(torch.uint8)).float().mean() > 0.999
 
 
+@pytest.mark.parametrize("M,N,K,swiglu", [(1, 6144, 4096, False), (3, 4096, 14336, False), (8, 28672, 4096, True), (16, 28672, 4096, True),
+                                           (13, 1280, 8192, False), (4, 128256, 4096, False), (5, 7168, 1024, True), (2, 48, 384, False)])
+def test_skinny_linear_w8_matches_the_dequantised_product(M, N, K, swiglu):
+    """W8A16 decode (`skinny_linear_kernel<…, W8>`): e4m3 weights streamed through LDS, widened to bf16 in registers (exact),
+    bf16 MFMA, per-output-channel scale in the epilogue — against the fp32 product with the dequantised weights."""
+    x = _bf(M, K, seed=85)
+    w = _bf(N, K, seed=86, scale=0.05)
+    wq, ws = ops.quant_weight_fp8(w)
+    got = ops.linear_w8(x, wq, ws, swiglu=swiglu).float()
+    h = x.float() @ (wq.float() * ws.t()).t()
+    want = torch.nn.functional.silu(h[:, :N // 2]) * h[:, N // 2:] if swiglu else h
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    assert (got - want).abs().max() / want.abs().max() < 1.5e-2
+    ref = x.float() @ w.float().t()                           # and the bf16 weights' product within e4m3 noise
+    ref = torch.nn.functional.silu(ref[:, :N // 2]) * ref[:, N // 2:] if swiglu else ref
+    assert torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0).item() > 0.997
+
+
 @pytest.mark.parametrize("M,N,K", [(2304, 6144, 4096), (70, 4096, 14336), (300, 28672, 4096)])
 def test_linear_fp8_tracks_fp32_reference(M, N, K):
     """W8A8 GEMM (per-token × per-channel scales, fp8 matrix cores through torch._scaled_mm) against the fp32 product of the
