@@ -100,6 +100,8 @@ def parse(argv=None):
     ap.add_argument("--no-custom-ar", action="store_true")
     ap.add_argument("--quantization", default=None, choices=["fp8"],
                     help="W8A8 dense projections on the fp8 matrix cores (EngineConfig.quantization); NOT the headline config: the line is marked reduced precision")
+    ap.add_argument("--tune-library-gemms", default=None, metavar="FILE",
+                    help="PyTorch TunableOp results file: tune hipBLASLt / rocBLAS per GEMM shape at warm-up (EngineConfig.library_gemm_tuning)")
     ap.add_argument("--no-ttft-tpot-trade", action="store_true",
                     help="TPOT control as a fixed per-step cap (A/B of SchedulerConfig.ttft_tpot_trade)")
     ap.add_argument("--fcfs", action="store_true", help="plain FCFS admission (default: requests past their TTFT deadline yield)")
@@ -317,7 +319,8 @@ def main():
                                                ep_a2a_min_tokens=0 if args.emulate_tp > 1 else args.ep_a2a_min_tokens),
                        device=args.device, seed=args.seed, use_hip_graphs=on_gpu and not args.no_graphs,
                        async_scheduling=False if args.sync_steps else None, mixed_step_graphs=not args.no_mixed_graphs,
-                       tune_gemms=not args.no_gemm_tune, quantization=args.quantization)
+                       tune_gemms=not args.no_gemm_tune, quantization=args.quantization,
+                       library_gemm_tuning=args.tune_library_gemms)
     t_load = time.perf_counter()
     eng = LLMEngine(cfg, ctx, dev)
     note(f"model built in {time.perf_counter() - t_load:.1f} s, {eng.runner.kv_cache_tokens} KV tokens; warming up")

@@ -199,6 +199,11 @@ class EngineConfig:
     # steps of more than 64 rows; decode-sized steps keep the bf16 weight-streaming kernels (both copies stay resident:
     # 288 GB).  None: bf16 throughout (the default, and what every headline number is measured with).
     quantization: Optional[str] = None
+    # Path of a PyTorch TunableOp results file: the vendor-library GEMMs (hipBLASLt / rocBLAS behind torch) are tuned per
+    # shape during warm-up (seconds per shape on the first start; the file is written and simply loaded by later starts),
+    # and the measured dispatch (ops/gemm_plan.py) then times the TUNED library against the own tile.  None: the library's
+    # own heuristics.  Probe on this GPU: −4…6 % on the long-K shapes at M ≈ 2300, −35 % at 256 × 6144 × 4096, else flat.
+    library_gemm_tuning: Optional[str] = None
     tokenizer_path: Optional[str] = None    # HF tokenizer.json; None → byte-level tokenizer
 
 

@@ -857,6 +857,22 @@ class ModelRunner:
             return {}
         plan = gemm_plan.PLAN
         blob = None
+        tunable = None
+        if self.cfg.library_gemm_tuning:                     # every rank tunes its own shard shapes (the first GEMM call of a shape does it)
+            import torch.cuda.tunable as tunable
+            path = self.cfg.library_gemm_tuning if self.ctx.tp_size == 1 else f"{self.cfg.library_gemm_tuning}.rank{self.ctx.tp_rank}"
+            t0 = time.perf_counter()
+            tunable.enable(True)
+            tunable.set_filename(path)
+            if os.path.exists(path):
+                tunable.read_file(path)
+            tunable.tuning_enable(True)
+            tunable.set_max_tuning_iterations(20)
+            tunable.set_max_tuning_duration(200)
+            if hasattr(tunable, "write_file_on_exit"):
+                tunable.write_file_on_exit(True)
+            if not self.ctx.is_driver:                       # the driver's timing sweep below touches every shape; workers do it here
+                self._touch_library_gemms()
         if self.ctx.is_driver:
             from ..models.llama import Attention, SwiGLUMLP
             groups: dict = {}
@@ -875,7 +891,8 @@ class ModelRunner:
             B = self.cfg.sched.max_num_seqs
             decode_rows = [b for b in self.cfg.graph_batch_sizes if b <= B]
             rows = sorted(set(decode_rows) | set(self.mixed_buckets if self.cfg.mixed_step_graphs else ()))
-            plan.tune([(k[0], v, k[2]) for k, v in groups.items()], rows, self.device)
+            plan.tune([(k[0], v, k[2]) for k, v in groups.items()], rows, self.device,
+                      budget_s=300.0 if tunable is not None else 60.0)   # a first start with library tuning spends seconds per shape
             head = getattr(self.model, "lm_head", None)
             if head is not None and getattr(head, "weight", None) is not None:
                 plan.tune([("lm_head", [head.weight.data], False)], decode_rows, self.device, budget_s=20.0)
@@ -885,7 +902,30 @@ class ModelRunner:
             if not self.ctx.is_driver:
                 plan.load(blob)
         self.selftest["gemm_plan"] = plan.summary() if self.ctx.is_driver else {"entries": sum(len(v) - 1 for v in plan.table.values())}
+        if tunable is not None:
+            tunable.tuning_enable(False)                     # shapes first seen later (eager fall-backs) take the default solution
+            try:
+                if hasattr(tunable, "write_file"):
+                    tunable.write_file()
+            except Exception as e:                           # a read-only location: the tuning still holds for this process
+                print(f"[dli_amd] could not write the TunableOp results: {e}", flush=True)
+            self.selftest["gemm_plan"]["library_tuning"] = {"file": self.cfg.library_gemm_tuning, "entries": len(tunable.get_results()),
+                                                            "seconds": round(time.perf_counter() - t0, 1)}
         return self.selftest["gemm_plan"]
+
+    def _touch_library_gemms(self) -> None:
+        """One library GEMM per (projection shape, captured row count): what TunableOp needs to see to tune them."""
+        from ..models.layers import ColumnParallelLinear, RowParallelLinear
+        import torch.nn.functional as F
+        B = self.cfg.sched.max_num_seqs
+        rows = sorted({b for b in self.cfg.graph_batch_sizes if 64 < b <= B} | set(self.mixed_buckets if self.cfg.mixed_step_graphs else ()))
+        seen = set()
+        for mod in self.model.modules():
+            if isinstance(mod, (ColumnParallelLinear, RowParallelLinear)) and tuple(mod.weight.data.shape) not in seen:
+                seen.add(tuple(mod.weight.data.shape))
+                for m in rows:
+                    F.linear(torch.zeros(m, mod.weight.data.shape[1], device=self.device, dtype=self.dtype), mod.weight.data)
+        torch.cuda.synchronize()
 
     @torch.inference_mode()
     def selftest_overlap(self) -> dict:

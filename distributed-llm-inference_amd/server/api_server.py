@@ -477,7 +477,8 @@ def engine_config_from_args(a) -> EngineConfig:
                               tpot_slo=a.tpot_slo, max_queue_delay=a.max_queue_delay),
         parallel=ParallelConfig(tp=a.tp, ep=a.ep, custom_all_reduce=not a.no_custom_all_reduce),
         device=a.device, seed=a.seed, use_hip_graphs=not a.no_hip_graphs, weights_path=a.weights,
-        tokenizer_path=a.tokenizer, quantization=getattr(a, "quantization", None))
+        tokenizer_path=a.tokenizer, quantization=getattr(a, "quantization", None),
+        library_gemm_tuning=getattr(a, "tune_library_gemms", None))
 
 
 def add_engine_args(ap: argparse.ArgumentParser):
@@ -488,6 +489,8 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--tp", type=int, default=1)
     ap.add_argument("--ep", type=int, default=1)
     ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8"])
+    ap.add_argument("--tune-library-gemms", default=None, metavar="FILE",
+                    help="PyTorch TunableOp results file: tune the vendor GEMMs per shape at the first start, load the file afterwards")
     ap.add_argument("--quantization", default=None, choices=["fp8"],
                     help="W8A8: dense projections in OCP e4m3 (per-channel weight scales, per-token activation scales) for steps above 64 rows")
     ap.add_argument("--kv-calibration-file", default=None,
