@@ -1,5 +1,6 @@
 """End-to-end GPU checks of the engine on a small D=128 Llama: the HIP-kernel
 forward against the fp32 torch-reference forward, hipGraph decode against eager decode, fp8 KV."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -271,3 +272,25 @@ def test_fp8_w8a8_engine_on_gpu_tracks_the_bf16_engine(tmp_path):
     assert 0.99 < cos < 1.0, cos
     first = np.mean([a[0] == b[0] for a, b in zip(outs["bf16"], outs["fp8"])])
     assert first >= 2 / 3, (outs, first)
+
+
+def test_library_gemm_tuning_writes_and_reloads_its_file(tmp_path):
+    """`--tune-library-gemms FILE` (PyTorch TunableOp under the measured dispatch): a first start tunes the vendor GEMMs of the
+    captured shapes and writes FILE, a second start loads it; both serve.  (Own process: TunableOp is process-global state.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    f = str(tmp_path / "tunable.csv")
+    lines = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "tiny-llama-tp", "--steps", "5", "--warmup", "2", "--qps", "20",
+                            "--ramp-seconds", "2", "--ramp-cap-seconds", "2", "--sustained-seconds", "2", "--max-num-seqs", "128",
+                            "--max-batched-tokens", "512", "--tune-library-gemms", f], capture_output=True, text=True, timeout=250, cwd=root)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for line in lines:
+        lt = line["selftest"]["gemm_plan"]["library_tuning"]
+        assert lt["file"] == f and lt["entries"] >= 1 and line["rank0"]["finished"] >= 0
+    assert os.path.exists(f) and os.path.getsize(f) > 0
+    assert lines[1]["selftest"]["gemm_plan"]["library_tuning"]["seconds"] <= lines[0]["selftest"]["gemm_plan"]["library_tuning"]["seconds"] + 5
