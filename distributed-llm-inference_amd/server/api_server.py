@@ -498,7 +498,8 @@ def add_engine_args(ap: argparse.ArgumentParser):
     ap.add_argument("--num-kv-blocks", type=int, default=None)
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.92)
     ap.add_argument("--no-prefix-caching", action="store_true")
-    ap.add_argument("--max-num-seqs", type=int, default=1024)
+    ap.add_argument("--max-num-seqs", type=int, default=2048,
+                    help="sequences running at once (rows of a decode step); one MI355X holds 1.9 M tokens of bf16 KV for Llama-3-8B")
     ap.add_argument("--max-num-batched-tokens", type=int, default=4096)
     ap.add_argument("--max-model-len", type=int, default=4096)
     ap.add_argument("--max-position", type=int, default=None)
