@@ -179,7 +179,7 @@ def attach_decode_worklist(meta: AttnMetadata, seq_lens: np.ndarray, num_heads: 
     """Tests / benchmarks: build the decode work list of ``seq_lens`` (host copy of the first ``meta.num_decode`` rows)
     and hang it — device tensors, workspace, counts — on ``meta``.  ``launch_items`` > 0 launches that many workgroups
     per kv head instead of the exact count (what a hipGraph does); the kernel takes the valid count from ``counts``."""
-    work, red, n_parts = build_decode_work(seq_lens, num_kv_heads, cap_items, chunk_pages)
+    work, red, _ = build_decode_work(seq_lens, num_kv_heads, cap_items, chunk_pages)
     n_items, n_reds = len(work), len(red)
     li = max(launch_items, n_items)
     lr = max(launch_items, n_reds) if launch_items else n_reds

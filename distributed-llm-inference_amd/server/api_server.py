@@ -218,7 +218,6 @@ class ApiServer:
                                 break
                         if item.finished:
                             reason = item.reason or "stop"
-                            n_prompt = item.n_prompt
                 finally:
                     await agen.aclose()                              # early exit (stop string, client gone): abort in the engine
                 t_end = time.perf_counter_ns()
