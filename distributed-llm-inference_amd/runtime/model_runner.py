@@ -112,9 +112,12 @@ class ModelRunner:
         sharing = (max(group, job) + n_dev - 1) // n_dev
         if sharing > 1:
             # whatever the others have loaded so far: an equal share of the device minus what THIS rank holds besides its cache
+            # — and only 55 % of that share: every rank's hipGraph pools (≈ 11 GB each for a Mixtral shard at 8192-token
+            # steps) come out of the same card, and a rehearsal needs no large cache (8 ranks of Mixtral at real shapes ran
+            # the card out of memory during capture with the full share)
             mine = torch.cuda.memory_allocated(self.device)
             budget = min((budget - (sharing - 1) * reserve) / sharing,
-                         total * c.cache.gpu_memory_utilization / sharing - mine - reserve)
+                         0.55 * total * c.cache.gpu_memory_utilization / sharing - mine - reserve)
         n = int(budget // per_block)
         if n < self.max_blocks_per_seq:
             raise RuntimeError(f"not enough HBM for the KV cache: {budget / 2**30:.1f} GiB left after weights")
@@ -1119,6 +1122,9 @@ class ModelRunner:
             torch.cuda.synchronize()
         except Exception as e:                               # e.g. a collective that cannot be captured on this backend
             err = f"{type(e).__name__}: {e}"
+            # say so NOW: peers that did not fail may sit in a collective of their next warm-up run until its time-out,
+            # and the vote below only completes after that
+            print(f"[dli_amd] tp rank {self.ctx.tp_rank}: graph capture failed: {err}", flush=True)
         if not self._vote(err is None):                      # all ranks keep their graphs, or none does
             self.selftest["graph_capture"] = {"ok": False, "error": err or "failed on another rank"}
             print(f"[dli_amd] hipGraph capture failed ({self.selftest['graph_capture']['error']}): steps run eagerly",
