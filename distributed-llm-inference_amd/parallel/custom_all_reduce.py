@@ -153,6 +153,9 @@ class CustomAllReduce:
         """Most tokens of a step one ``ep_moe`` call can take: in the worst routing every (token, expert) row lands on ONE
         rank, whose result buffer (``max_bytes``) must hold them all."""
         t = self.max_bytes // (top_k * hidden * 2)
+        forced = int(os.environ.get("DLI_EP_TOKENS_PER_CALL", "0"))      # tests: exercise the several-calls-per-step path
+        if forced > 0:
+            t = min(t, forced)
         return max(t // (self.world * 8) * (self.world * 8), 0)
 
     def ep_moe(self, x_l: torch.Tensor, logits_l: torch.Tensor, w13: torch.Tensor, w2: torch.Tensor, top_k: int,

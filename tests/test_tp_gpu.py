@@ -149,6 +149,27 @@ def test_tp2_real_shapes_logits_track_tp1(model, ep, a2a, tmp_path):
     assert cos > 0.9995, cos
 
 
+@pytest.mark.parametrize("sp", [False, True])
+def test_ep_dispatch_in_several_calls_per_step(sp, tmp_path):
+    """A step larger than one IPC exchange can carry (`CustomAllReduce.ep_tokens_per_call`; Mixtral at 8192-token steps: two
+    calls) goes through the dispatch in pieces — forced here to 128 tokens per call on a 1074-token step — with and
+    without the sequence-parallel norms (which then take this rank's rows out of the re-assembled result).  Logits against
+    the replicated path."""
+    rng = np.random.default_rng(13)
+    prompts = [rng.integers(3, 1000, size=n).tolist() for n in (700, 333, 41)]
+    logits = {}
+    sp_env = {"DLI_SP_FORCE": "1", "DLI_SP_MIN_BYTES": "65536"} if sp else {"DLI_SP_NORM": "0"}
+    for name, env in (("pieces", {"DLI_TEST_EP_A2A": "64", "DLI_EP_TOKENS_PER_CALL": "128"}), ("replicated", {"DLI_TEST_EP_A2A": "0"})):
+        f = str(tmp_path / f"logits_{name}.pt")
+        out = run("tiny-mixtral-tp", 2, 2, prompts, dict(env, DLI_DUMP_LOGITS=f, DLI_OVERLAP_MIN_ROWS="1000000", **sp_env))
+        if name == "pieces":
+            assert out["a2a_calls"] >= 2 * 2 * 9 and out["mixed_graph_steps"] > 0      # 9 pieces × 2 layers × (dispatch + combine)
+            assert (out["sp_norm_calls"] > 0) == sp
+        logits[name] = torch.load(f, weights_only=True)
+    cos = torch.nn.functional.cosine_similarity(logits["pieces"], logits["replicated"], dim=0).item()
+    assert cos > 0.999, cos
+
+
 def test_tp2_w8a8_tracks_tp1_w8a8_and_bf16(tmp_path):
     """`quantization="fp8"` under tensor parallelism: every rank quantises its own shards (column-parallel: the same
     per-channel scales as the unsharded matrix; row-parallel: scales over the rank's K slice, activations quantised per
