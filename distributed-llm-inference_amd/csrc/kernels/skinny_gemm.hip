@@ -82,7 +82,7 @@ __device__ __forceinline__ float skinny_dot(const char* const (&xsrc)[XI], const
   const int xr = r & (XROWS - 1);                      // columns ≥ XROWS alias loaded rows (never stored)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (W8) frag_off[j] = XI * 1024 + r * 128 + ((((4 * j + g) >> 1) ^ (r & 7)) << 4) + ((4 * j + g) & 1) * 8;
+    if (W8) frag_off[j] = XI * 1024 + r * 128 + ((((4 * j + g) >> 1) ^ ((r >> 1) & 7)) << 4) + ((4 * j + g) & 1) * 8;   // key: see the kernel's wsrc
     else frag_off[j] = XI * 1024 + r * 256 + (((4 * j + g) ^ r) << 4);
     xfrag_off[j] = xr * 256 + (((4 * j + g) ^ x_swz<XI>(xr)) << 4);
   }
@@ -156,7 +156,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_linear_kernel(const uint16_t* 
   for (int i = 0; i < (W8 ? 2 : 4); ++i) {
     const int row = W8 ? 8 * i + (lane >> 3) : 4 * i + g;
     const int wrow = SWIGLU ? (row < 8 ? n0 + row : (N >> 1) + n0 + row - 8) : n0 + row;
-    if (W8) wsrc[i] = reinterpret_cast<const char*>(w_) + (int64_t)wrow * K + (((lane & 7) ^ (row & 7)) << 4);
+    // e4m3 rows are 128 B = half a bank line: rows of equal parity share their banks, so the swizzle key is (row >> 1) & 7 —
+    // distinct over the 8 rows that do (with row & 7 rows r and r + 8 collided: 0.23 LDS conflict cycles per active cycle)
+    if (W8) wsrc[i] = reinterpret_cast<const char*>(w_) + (int64_t)wrow * K + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
     else wsrc[i] = reinterpret_cast<const char*>(reinterpret_cast<const uint16_t*>(w_) + (int64_t)wrow * K) + ((r ^ row) << 4);
   }
   // More than 16 tokens: further passes over the same 16 weight rows, 16 tokens each.  The workgroup re-reads the
