@@ -11,6 +11,8 @@ void launch_rms_norm(void* out, const void* x, const void* w, float eps, int row
 void launch_fused_add_rms_norm(void* x, void* residual, const void* w, float eps, int rows, int H, int64_t x_stride,
                                hipStream_t stream);
 void launch_silu_and_mul(void* out, const void* x, int rows, int inter, int64_t x_stride, hipStream_t stream);
+void launch_rms_norm_quant(const void* x, void* residual, const void* w, float eps, int rows, int H, int64_t x_stride, void* q,
+                           float* scales, hipStream_t stream);
 void launch_quant_rows_fp8(bool silu, const void* x, int64_t x_stride, void* q, int64_t q_stride, float* scales, int rows,
                            int K, hipStream_t stream);
 

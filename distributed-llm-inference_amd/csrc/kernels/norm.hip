@@ -12,10 +12,14 @@ namespace dli {
 constexpr int NT = 256;
 constexpr int MAXV = 4;   // register-cached vectors per thread → H <= 256*8*4 = 8192 in one pass
 
-template <bool ADD_RESIDUAL>
+// QUANT (W8A8 option): the normalised row is not stored in bf16 but quantised per row to OCP e4m3 — q[row] = e4m3(y · 448 /
+// max|y|), scales[row] = max|y| / 448 with y the bf16-rounded normalised row (the numbers the unfused norm → quant_rows_fp8
+// pair would produce) — so the quantisation pass and the bf16 round trip of the GEMM input disappear.  H ≤ 8192 only.
+template <bool ADD_RESIDUAL, bool QUANT = false>
 __global__ __launch_bounds__(NT) void rms_norm_kernel(uint16_t* out, const uint16_t* x,   // may alias (in-place form)
                                                       uint16_t* residual, const uint16_t* __restrict__ w,
-                                                      float eps, int H, int64_t x_stride, int64_t out_stride) {
+                                                      float eps, int H, int64_t x_stride, int64_t out_stride,
+                                                      uint8_t* __restrict__ q = nullptr, float* __restrict__ scales = nullptr) {
   __shared__ float red[NT / 64];
   const int64_t row = blockIdx.x;
   const uint16_t* xr = x + row * x_stride;
@@ -70,6 +74,44 @@ __global__ __launch_bounds__(NT) void rms_norm_kernel(uint16_t* out, const uint1
   const float tot = block_sum<NT>(ss, red);
   const float inv = rsqrtf(tot / (float)H + eps);
 
+  if constexpr (QUANT) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = threadIdx.x + i * NT;
+      if (v < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          vals[i][j] = bf2f(f2bf(vals[i][j] * inv * bf2f((uint16_t)gw[i][j])));
+          amax = fmaxf(amax, fabsf(vals[i][j]));
+        }
+      }
+    }
+    amax = wave_max(amax);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-12f);
+    const float qinv = 448.f / amax;
+    if (threadIdx.x == 0) scales[row] = amax * (1.f / 448.f);
+    uint8_t* qr = q + row * (int64_t)H;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = threadIdx.x + i * NT;
+      if (v < nvec) {
+        float c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = fminf(fmaxf(vals[i][j] * qinv, -448.f), 448.f);
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+        *reinterpret_cast<u32x2*>(qr + (int64_t)v * 8) = u32x2{(unsigned)lo, (unsigned)hi};
+      }
+    }
+    return;
+  }
+
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = threadIdx.x + i * NT;
@@ -103,6 +145,19 @@ void launch_fused_add_rms_norm(void* x, void* residual, const void* w, float eps
   if (rows == 0) return;
   hipLaunchKernelGGL(rms_norm_kernel<true>, dim3(rows), dim3(NT), 0, stream, (uint16_t*)x, (const uint16_t*)x,
                      (uint16_t*)residual, (const uint16_t*)w, eps, H, x_stride, x_stride);
+}
+
+// W8A8 option: (residual += x;) q, scales = quantise(rmsnorm(·) · w) — see rms_norm_kernel<…, QUANT>.  residual == nullptr: plain
+// norm of x.  H ≤ 8192, H % 8 == 0.  x is left untouched.
+void launch_rms_norm_quant(const void* x, void* residual, const void* w, float eps, int rows, int H, int64_t x_stride, void* q,
+                           float* scales, hipStream_t stream) {
+  if (rows == 0) return;
+  if (residual != nullptr)
+    hipLaunchKernelGGL((rms_norm_kernel<true, true>), dim3(rows), dim3(NT), 0, stream, (uint16_t*)nullptr, (const uint16_t*)x,
+                       (uint16_t*)residual, (const uint16_t*)w, eps, H, x_stride, (int64_t)0, (uint8_t*)q, scales);
+  else
+    hipLaunchKernelGGL((rms_norm_kernel<false, true>), dim3(rows), dim3(NT), 0, stream, (uint16_t*)nullptr, (const uint16_t*)x,
+                       (uint16_t*)nullptr, (const uint16_t*)w, eps, H, x_stride, (int64_t)0, (uint8_t*)q, scales);
 }
 
 }  // namespace dli

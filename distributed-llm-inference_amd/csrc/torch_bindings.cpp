@@ -68,6 +68,25 @@ std::tuple<Tensor, Tensor> quant_rows_fp8(const Tensor& x, bool silu) {
   return {q, scales};
 }
 
+// (residual += x;) rmsnorm(·)·w quantised per row to e4m3 in one kernel (norm.hip, QUANT): (q [rows, H], scales [rows, 1]).
+std::tuple<Tensor, Tensor> rms_norm_quant(const Tensor& x, const c10::optional<Tensor>& residual, const Tensor& weight, double eps) {
+  check_bf16_rows(x, "x");
+  const int64_t rows = x.size(0), H = x.size(1);
+  TORCH_CHECK(H % 16 == 0 && H <= 8192 && weight.numel() == H && weight.scalar_type() == at::kBFloat16 && weight.is_contiguous(),
+              "rms_norm_quant: H must be a multiple of 16, at most 8192");
+  void* res = nullptr;
+  if (residual.has_value()) {
+    check_bf16_rows(*residual, "residual");
+    TORCH_CHECK(residual->is_contiguous() && residual->sizes() == x.sizes(), "residual must be contiguous and shaped like x");
+    res = residual->data_ptr();
+  }
+  Tensor q = at::empty({rows, H}, x.options().dtype(at::kFloat8_e4m3fn));
+  Tensor scales = at::empty({rows, 1}, x.options().dtype(at::kFloat));
+  dli::launch_rms_norm_quant(x.data_ptr(), res, weight.data_ptr(), (float)eps, (int)rows, (int)H, x.stride(0), q.data_ptr(),
+                             scales.data_ptr<float>(), cur_stream(x));
+  return {q, scales};
+}
+
 // y = x · Wᵀ (+ bias) for decode-sized x (≤ 16 rows): the weight-streaming kernel in kernels/skinny_gemm.hip
 // `out` (optional): write the result there instead of a fresh tensor — the row-parallel layers hand in a view of the custom
 // all-reduce's IPC staging buffer, so the reduction reads the GEMM's output in place.
@@ -581,6 +600,7 @@ TORCH_LIBRARY(dli, m) {
   m.def("fused_add_rms_norm(Tensor(a!) x, Tensor(b!) residual, Tensor weight, float eps) -> ()", &fused_add_rms_norm);
   m.def("silu_and_mul(Tensor x) -> Tensor", &silu_and_mul);
   m.def("quant_rows_fp8(Tensor x, bool silu=False) -> (Tensor, Tensor)", &quant_rows_fp8);
+  m.def("rms_norm_quant(Tensor x, Tensor(a!)? residual, Tensor weight, float eps) -> (Tensor, Tensor)", &rms_norm_quant);
   m.def("skinny_linear(Tensor x, Tensor w, Tensor? bias, bool swiglu=False, Tensor? out=None, Tensor? w_scale=None) -> Tensor", &skinny_linear);
   m.def("dense_gemm256(Tensor x, Tensor w, bool swiglu=False, int k_splits=1, Tensor? out=None, bool split_tail=False) -> Tensor", &dense_gemm256);
   m.def("ar_staging_tensor(int state, int rows, int cols, Tensor like) -> Tensor", &ar_staging_tensor);

@@ -22,6 +22,8 @@ Expert parallelism (``ctx.ep_size == tp``): each rank owns ``E/tp`` whole expert
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -53,6 +55,9 @@ def _rank_check(ctx, tag, t):
 def _ep_consistency_check(ctx, h, logits):
     _rank_check(ctx, "moe-input", h)
     _rank_check(ctx, "router-logits", logits)
+
+
+FUSE_NORM_QUANT = os.environ.get("DLI_FUSE_NORM_QUANT", "1") != "0"     # A/B knob of the W8A8 option
 
 
 class Attention(nn.Module):
@@ -105,8 +110,9 @@ class Attention(nn.Module):
         self.sat_count = n if self.sat_count is None else self.sat_count + n
         self.sat_total = (self.sat_total or 0) + k.numel() + v.numel()
 
-    def forward(self, h, meta, kv, cos_sin):
-        qkv = self.qkv(h)
+    def forward(self, h, meta, kv, cos_sin, xq=None):
+        """``xq``: the layer input already quantised to e4m3 by the fused norm (W8A8 option); ``h`` is then not read."""
+        qkv = self.qkv(h, xq=xq)
         k_cache, v_cache = kv
         if self.calibrating and self.kv_scales is not None:
             self._observe(qkv)
@@ -126,11 +132,11 @@ class SwiGLUMLP(nn.Module):
                                             ctx, dtype, device)
         self.down = RowParallelLinear(cfg.intermediate_size, cfg.hidden_size, ctx, dtype, device)
 
-    def forward(self, h):
+    def forward(self, h, xq=None):
         w13 = self.gate_up.weight
-        if w13.q is not None and ops.use_fp8(h):
+        if xq is not None or (w13.q is not None and ops.use_fp8(h)):
             # W8A8: gate/up on the fp8 matrix cores, then ONE pass that applies SwiGLU and quantises the down projection's input
-            gu = ops.linear_fp8(h, w13.q, w13.q_scale)
+            gu = ops.linear_fp8(h, w13.q, w13.q_scale, xq=xq)
             return self.down(gu, defer=True, xq=ops.quant_rows_fp8(gu, silu=True))
         if w13.q is not None and ops.skinny_w8_ok(h, w13.q, 32):
             return self.down(ops.linear_w8(h, w13.q, w13.q_scale, swiglu=True), defer=True)     # decode: e4m3 weight stream
@@ -260,17 +266,33 @@ class DecoderLayer(nn.Module):
 
     def forward(self, h, residual, meta, kv, cos_sin):
         ctx = self.attn.o.ctx
+        # W8A8 option, dense layers, steps that take the fp8 GEMMs: the norms hand their rows to the projections as e4m3
+        # (one kernel: add + norm + per-row quantisation) — unless the input is an un-reduced partial sum (sequence-parallel
+        # steps fuse the norm with the reduction instead)
+        fuse_q = self.fuse_norm_quant and not isinstance(h, Partial) and ops.use_fp8(h) and h.shape[1] <= 8192
         if residual is None:
             residual = h
-            h = ops.rms_norm(h, self.input_norm.data, self.eps)
+            if fuse_q:
+                h = self.attn(None, meta, kv, cos_sin, xq=ops.rms_norm_quant(h, None, self.input_norm.data, self.eps))
+            else:
+                h = self.attn(ops.rms_norm(h, self.input_norm.data, self.eps), meta, kv, cos_sin)
+        elif fuse_q:
+            h = self.attn(None, meta, kv, cos_sin, xq=ops.rms_norm_quant(h, residual, self.input_norm.data, self.eps))
         else:
             h = add_norm(h, residual, self.input_norm.data, self.eps, ctx)   # h: the previous layer's MLP output, maybe un-reduced
-        h = self.attn(h, meta, kv, cos_sin)
+            h = self.attn(h, meta, kv, cos_sin)
         if not isinstance(h, Partial):
             _rank_check(ctx, "attn-out", h)
+            if fuse_q:
+                return self.mlp(None, xq=ops.rms_norm_quant(h, residual, self.post_norm.data, self.eps)), residual
         h = add_norm(h, residual, self.post_norm.data, self.eps, ctx)
         h = self.mlp(h)
         return h, residual
+
+    @property
+    def fuse_norm_quant(self) -> bool:
+        return (FUSE_NORM_QUANT and isinstance(self.mlp, SwiGLUMLP) and self.attn.qkv.weight.q is not None
+                and self.attn.qkv.bias is None)
 
 
 class LlamaForCausalLM(nn.Module):

@@ -299,6 +299,20 @@ def quant_rows_fp8(x: torch.Tensor, silu: bool = False):
     return (xf / scale).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn), scale
 
 
+def rms_norm_quant(x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float):
+    """``residual += x`` (when given), then ``quant_rows_fp8(rmsnorm(residual or x) * weight)`` — one kernel on the GPU
+    (``rms_norm_kernel<…, QUANT>``): the normalised row goes straight to e4m3, it is never stored in bf16.  ``x`` is left
+    untouched.  Returns ``(q, scale)`` for ``linear_fp8(xq=…)``."""
+    if _gpu_kernel_ok(x) and x.shape[1] <= 8192 and x.shape[1] % 16 == 0 and x.stride(1) == 1:
+        return hip().rms_norm_quant(x, residual, weight, eps)
+    if residual is not None:
+        y = x.clone()
+        fused_add_rms_norm(y, residual, weight, eps)
+    else:
+        y = rms_norm(x, weight, eps)
+    return quant_rows_fp8(y)
+
+
 def quant_weight_fp8(w: torch.Tensor):
     """One scale per output channel: ``(q [N, K] float8_e4m3fn, scale [1, N] fp32)``."""
     wf = w.float()

@@ -467,6 +467,27 @@ def test_quant_rows_fp8_matches_reference(M, K, silu):
         assert (q.view(torch.uint8) == want_q.view(torch.uint8)).float().mean() > 0.999
 
 
+@pytest.mark.parametrize("T,H,add", [(70, 4096, True), (300, 8192, True), (33, 1024, False), (5, 4096, True)])
+def test_rms_norm_quant_equals_norm_then_quant(T, H, add):
+    """W8A8 option: (residual add +) RMSNorm + per-row e4m3 quantisation in ONE kernel against the two kernels it replaces
+    — same residual, same scales, same codes (the fused kernel quantises the bf16-rounded normalised row)."""
+    x = _bf(T, H, seed=91)
+    w = (1 + 0.1 * torch.randn(H, device=DEV)).to(torch.bfloat16)
+    res = _bf(T, H, seed=92) if add else None
+    r1 = res.clone() if add else None
+    q, s = ops.hip().rms_norm_quant(x, r1, w, 1e-5)
+    y = x.clone()
+    if add:
+        r2 = res.clone()
+        ops.fused_add_rms_norm(y, r2, w, 1e-5)
+        assert torch.equal(r1, r2)
+    else:
+        y = ops.rms_norm(x, w, 1e-5)
+    q2, s2 = ops.hip().quant_rows_fp8(y, False)
+    assert torch.equal(s, s2) and torch.equal(q.view(torch.uint8), q2.view(torch.uint8))
+    assert torch.equal(x, _bf(T, H, seed=91))                 # the input is left alone
+
+
 @pytest.mark.parametrize("M,N,K,swiglu", [(1, 6144, 4096, False), (3, 4096, 14336, False), (8, 28672, 4096, True), (16, 28672, 4096, True),
                                            (13, 1280, 8192, False), (4, 128256, 4096, False), (5, 7168, 1024, True), (2, 48, 384, False)])
 def test_skinny_linear_w8_matches_the_dequantised_product(M, N, K, swiglu):
