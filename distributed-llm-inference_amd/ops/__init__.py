@@ -276,6 +276,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return torch.nn.functional.linear(x, weight, bias)
 
 
+# Stream-capture error mode of every hipGraph capture in the package.  "global" (torch's default) makes a capture-unsafe HIP call
+# on ANY thread fail while a capture is open — and the RCCL process group's watchdog thread polls its work events with
+# hipEventQuery from its own thread: caught on the one-GPU box with a one-rank RCCL group (tests/test_rccl_gpu.py: "operation
+# not permitted when stream is capturing" in the watchdog → terminate), timing-dependent.  "thread_local" polices the capturing
+# thread only.  (The second half of the same problem — the watchdog polling an eager collective's event after the group's
+# stream has joined a capture — is parallel.state.drain_collectives, called before every capture.)
+CAPTURE_MODE = os.environ.get("DLI_CAPTURE_MODE", "thread_local")
+
 FP8_MIN_ROWS = int(os.environ.get("DLI_FP8_MIN_ROWS", "17"))      # below: the weight-streaming kernel (e4m3 weights, bf16 activations)
 FP8_MAX = 448.0                                                   # largest finite OCP e4m3 value
 

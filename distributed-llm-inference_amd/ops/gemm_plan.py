@@ -26,6 +26,7 @@ from typing import Optional
 import torch
 
 ENABLED = os.environ.get("DLI_GEMM_TUNE", "1") != "0"
+CAPTURE_MODE = os.environ.get("DLI_CAPTURE_MODE", "thread_local")     # see ops.CAPTURE_MODE
 MIN_ROWS = 65                 # at and below 64 rows the weight-streaming kernel (skinny_gemm.hip) has its own rules
 TAIL = 100                    # table value: plain tiles for the whole rounds, K-split remainder (dense_gemm256 split_tail)
 NUM_CU = 256
@@ -134,7 +135,7 @@ class GemmPlan:
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.graph(g, stream=s):
+        with torch.cuda.graph(g, stream=s, capture_error_mode=CAPTURE_MODE):
             for i in range(n):
                 fn(weights[i % len(weights)])
         torch.cuda.synchronize()

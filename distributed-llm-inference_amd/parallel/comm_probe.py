@@ -34,7 +34,7 @@ def _probe_main(a) -> dict:
     torch.cuda.set_device(dev)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{a.port}", rank=a.rank, world_size=a.world,
                             timeout=datetime.timedelta(seconds=a.timeout))
-    from dli_amd.parallel.state import ParallelContext
+    from dli_amd.parallel.state import ParallelContext, drain_collectives
 
     def vote(ok: bool) -> bool:
         votes = [None] * a.world
@@ -108,7 +108,8 @@ def _probe_main(a) -> dict:
                 g = torch.cuda.CUDAGraph()
                 s = torch.cuda.Stream(device=dev)
                 s.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.graph(g, stream=s):
+                drain_collectives()
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                     for _ in range(a.iters):
                         dist.all_reduce(x, group=nccl_group)
                 torch.cuda.synchronize()

@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
+from .state import drain_collectives
 
 _SIZES = (8 << 10, 32 << 10, 128 << 10, 512 << 10, 1 << 20, 2 << 20, 4 << 20, 8 << 20, 16 << 20, 32 << 20, 64 << 20)
 
@@ -222,7 +223,8 @@ class CustomAllReduce:
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.graph(g, stream=s):
+        drain_collectives()
+        with torch.cuda.graph(g, stream=s, capture_error_mode=ops.CAPTURE_MODE):
             for _ in range(iters):
                 fn()
         torch.cuda.synchronize()
@@ -260,7 +262,8 @@ class CustomAllReduce:
             g = torch.cuda.CUDAGraph()
             s = torch.cuda.Stream(device=self.device)
             s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(g, stream=s):
+            drain_collectives()
+            with torch.cuda.graph(g, stream=s, capture_error_mode=ops.CAPTURE_MODE):
                 dist.all_reduce(x, group=self.ctx.group)
             torch.cuda.synchronize()
         except Exception:

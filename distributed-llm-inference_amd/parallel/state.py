@@ -251,6 +251,29 @@ def init_distributed(backend: str = "auto", device: Optional[torch.device] = Non
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
 
 
+def drain_collectives() -> None:
+    """Call before opening a hipGraph capture: finish the device's work and let every RCCL group's watchdog thread retire the
+    collectives it still tracks.
+
+    The watchdog polls the end event of each EAGER collective with hipEventQuery until it has seen it complete, on its own ≈100 ms
+    cadence.  Those events sit on the group's internal stream; once that stream has joined a capture (a collective issued inside
+    the graph), HIP refuses the query — "operation not permitted on an event last recorded in a capturing stream" — and the
+    watchdog terminates the process.  Caught on the one-GPU box (tests/test_rccl_gpu.py), timing-dependent: only when a capture
+    opens within the poll interval after an eager warm-up collective.  ``_wait_for_pending_works`` returns when the watchdog's
+    list is empty; the works are complete after the synchronize, so it returns within one poll."""
+    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
+        return
+    torch.cuda.synchronize()
+    from torch.distributed.distributed_c10d import _world
+    for pg in list(_world.pg_map):
+        try:
+            is_rccl = "nccl" in str(dist.get_backend(pg))
+        except Exception:
+            continue
+        if is_rccl and hasattr(pg, "_wait_for_pending_works"):
+            pg._wait_for_pending_works()
+
+
 def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None, with_cpu_group: bool = True,
                     custom_all_reduce: bool = False, device: Optional[torch.device] = None,
                     all_groups: Optional[list] = None, device_backend: Optional[str] = None,

@@ -29,7 +29,7 @@ from ..config import EngineConfig, KV_BLOCK_SIZE
 from ..models import build_model, torch_dtype
 from ..ops import AttnMetadata
 from ..ops.kv_layout import allocate_kv_cache, bytes_per_block
-from ..parallel.state import SINGLE, ParallelContext
+from ..parallel.state import SINGLE, ParallelContext, drain_collectives
 
 
 _DUMP_LOGITS = __import__("os").environ.get("DLI_DUMP_LOGITS", "")
@@ -587,9 +587,10 @@ class ModelRunner:
                 run()
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
+        drain_collectives()                                  # the warm-up's RCCL calls: out of the watchdog before the capture
         g = torch.cuda.CUDAGraph()
         before = dict(self.ctx.comm)
-        with torch.cuda.graph(g, pool=self.graph_pool, stream=stream):
+        with torch.cuda.graph(g, pool=self.graph_pool, stream=stream, capture_error_mode=ops.CAPTURE_MODE):
             out = run()
         comm = {k: v - before[k] for k, v in self.ctx.comm.items() if v != before[k]}
         if self.graph_pool is None:

@@ -11,7 +11,7 @@ import torch.distributed as dist
 
 from dli_amd.config import CacheConfig, EngineConfig, ParallelConfig, SamplingParams, SchedulerConfig, get_model_config
 from dli_amd.engine.engine import LLMEngine
-from dli_amd.parallel.state import init_distributed, make_tp_context
+from dli_amd.parallel.state import drain_collectives, init_distributed, make_tp_context
 
 
 def main():
@@ -42,9 +42,9 @@ def main():
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             dist.all_reduce(z, group=ctx.group)              # warm-up on the capture stream
-        torch.cuda.synchronize()
+        drain_collectives()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=s):
+        with torch.cuda.graph(graph, stream=s, capture_error_mode="thread_local"):
             dist.all_reduce(z, group=ctx.group)
             w = z * 2
         z.copy_(x)
