@@ -30,7 +30,14 @@
 //     columns of one row: 8-byte row-contiguous stores, and the SwiGLU pair (gate column, up column) of a row
 //     lives in the same lane.
 //   * block → tile mapping: XCD x runs the x-th eighth of the tile order (8-column groups, row tile, column).
+//   * HALF tiles (grouped launches: an expert's last tile with at most 128 routed rows).  The schedule
+//     above stays as it is — same DMAs, same barriers, same counted waits — but the two wave groups share the 128 valid
+//     rows and split K instead of M: group 0 multiplies the first 32 columns of every 64-wide K-step, group 1 the second
+//     32 (half the fragment reads and half the MFMAs per phase for both), and group 1 hands its accumulators to group 0
+//     through the then idle 128 KB of LDS before the epilogue.  The half-tile loop is a second copy of the K loop, chosen
+//     per block from the alignment, so a full tile's instruction stream has no condition in it.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -102,8 +109,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   const uint16_t* We = W + (int64_t)e * w_expert_stride;
   const int n0 = col_block * (is_swiglu(EPI) ? TN / 2 : TN);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
   const int col = lane & 15, g = lane >> 4;
+  // at most 128 valid rows: the alignment pads an expert's rows at the END of its last tile
+  // (grouped launches carry the switch in lin_begin, which only the dense RANGE mode uses otherwise)
+  const bool half = GROUPED && lin_begin != 0 && sorted_ids[tile * TM + TM / 2] < 0;
+  const int wr_a = half ? 0 : wr;                            // wave row whose A rows this wave multiplies
 
   // ---- LDS-DMA sources.  A half-tile (a0, a1: 64 rows of each wave row; b0, b1: 32 rows of each wave column) is 128
   // rows = 16 pieces of 8 rows × 128 B = 1 KiB; wave w fills pieces 2w and 2w+1 of every half-tile.  Lane → row
@@ -161,14 +172,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   // fragment reads: A rows wr·128 + m·16 + col, B rows wc·64 + n·16 + col; chunk ks·4 + g of the 64-wide K-step
   // (row offsets that are multiples of 8 rows leave the swizzle term alone: two base addresses per operand — one per
   //  32-wide k half — and compile-time immediates for everything else)
-  const char* a_rd[2] = {lds + lds_off(wr * 128 + col, g), lds + lds_off(wr * 128 + col, 4 + g)};
+  const char* a_rd[2] = {lds + lds_off(wr_a * 128 + col, g), lds + lds_off(wr_a * 128 + col, 4 + g)};
   const char* b_rd[2] = {lds + STAGE_BYTES + lds_off(wc * 64 + col, g), lds + STAGE_BYTES + lds_off(wc * 64 + col, 4 + g)};
-#define G256_RD_A(dst_, buf_, half_)                                                                                 \
-  _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
-      dst_[m][ks] = *reinterpret_cast<const bf16x8*>(a_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 64 + m * 16) * 128);
-#define G256_RD_B(dst_, buf_, half_)                                                                                 \
-  _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
-      dst_[n][ks] = *reinterpret_cast<const bf16x8*>(b_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 32 + n * 16) * 128);
+  // (hm_: the half-tile copy of the loop — a wave touches the k half ks == wr only)
+#define G256_RD_A(dst_, buf_, half_, hm_)                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) if (!(hm_) || ks == wr)                                            \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                  \
+          dst_[m][ks] = *reinterpret_cast<const bf16x8*>(a_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 64 + m * 16) * 128);
+#define G256_RD_B(dst_, buf_, half_, hm_)                                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) if (!(hm_) || ks == wr)                                            \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                  \
+          dst_[n][ks] = *reinterpret_cast<const bf16x8*>(b_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 32 + n * 16) * 128);
   // end of a LOAD segment: my reads are complete before I pass the barrier (→ the half-tile may be re-filled)
 #define G256_END_LOAD()                                                                                              \
   {                                                                                                                  \
@@ -179,11 +193,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   }
   // MFMA segment: 16 MFMAs of one quadrant (k-step outermost: 8 independent accumulators between two uses of one),
   // then the counted DMA wait and the barrier
-#define G256_MMA(fa_, fb_, mh_, nh_, drain_)                                                                         \
+#define G256_MMA(fa_, fb_, mh_, nh_, drain_, hm_)                                                                    \
   {                                                                                                                  \
     __builtin_amdgcn_s_setprio(1);                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                    \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) if (!(hm_) || ks == wr)                                          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)                   \
             acc[(mh_) * 4 + m][(nh_) * 2 + n] = mfma16(fb_[n][ks], fa_[m][ks], acc[(mh_) * 4 + m][(nh_) * 2 + n]);    \
     __builtin_amdgcn_s_setprio(0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -199,27 +213,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   // DMA of step t+2 into this buffer, each half-tile right after both wave groups have read it: L0: bf (read one phase
   // before the step began), L1: a0, L2: bo, L3: a1 — 7 phases ahead of its first read.
   // (full_: a steady-state step, two more steps follow — no conditions at all in its instruction stream)
-#define G256_STEP(t_, buf_, full_)                                                                                   \
+#define G256_STEP(t_, buf_, full_, hm_)                                                                                  \
   {                                                                                                                  \
     constexpr int f_ = (buf_), o_ = 1 - (buf_);                                                                      \
     const bool drain_ = !(full_) && (t_) + 2 >= nk;           /* nothing more will be issued: counted waits would lie */ \
     const bool more_ = (full_) || (t_) + 2 < nk;                                                                     \
-    G256_RD_A(fa, buf_, 0);                                                                                          \
+    G256_RD_A(fa, buf_, 0, hm_);                                                                                          \
     if (more_) G256_STAGE_B((t_) + 2, buf_, f_);                                                                     \
     G256_END_LOAD();                                                                                                 \
-    G256_MMA(fa, fb[f_], 0, f_, drain_);                                                                             \
-    G256_RD_B(fb[o_], buf_, o_);                                                                                     \
+    G256_MMA(fa, fb[f_], 0, f_, drain_, hm_);                                                                             \
+    G256_RD_B(fb[o_], buf_, o_, hm_);                                                                                     \
     if (more_) G256_STAGE_A((t_) + 2, buf_, 0);                                                                      \
     G256_END_LOAD();                                                                                                 \
-    G256_MMA(fa, fb[o_], 0, o_, drain_);                                                                             \
-    G256_RD_A(fa, buf_, 1);                                                                                          \
+    G256_MMA(fa, fb[o_], 0, o_, drain_, hm_);                                                                             \
+    G256_RD_A(fa, buf_, 1, hm_);                                                                                          \
     if (more_) G256_STAGE_B((t_) + 2, buf_, o_);                                                                     \
     G256_END_LOAD();                                                                                                 \
-    G256_MMA(fa, fb[o_], 1, o_, drain_);                                                                             \
-    if ((full_) || (t_) + 1 < nk) G256_RD_B(fb[o_], (buf_) ^ 1, o_);                                                 \
+    G256_MMA(fa, fb[o_], 1, o_, drain_, hm_);                                                                             \
+    if ((full_) || (t_) + 1 < nk) G256_RD_B(fb[o_], (buf_) ^ 1, o_, hm_);                                                 \
     if (more_) G256_STAGE_A((t_) + 2, buf_, 1);                                                                      \
     G256_END_LOAD();                                                                                                 \
-    G256_MMA(fa, fb[f_], 1, f_, drain_);                                                                             \
+    G256_MMA(fa, fb[f_], 1, f_, drain_, hm_);                                                                             \
   }
 
   bf16x8 fa[4][2], fb[2][2][2];                              // a0 or a1 (64 rows); fb[h]: b half h (32 weight rows)
@@ -240,7 +254,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  G256_RD_B(fb[0], 0, 0);
+  if (half) {
+    G256_RD_B(fb[0], 0, 0, 1);
+  } else {
+    G256_RD_B(fb[0], 0, 0, 0);
+  }
   if (wr == 1) {                                               // the stagger: waves 4–7 run one segment behind
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -248,14 +266,41 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   __builtin_amdgcn_sched_barrier(0);
 
   int t = 0;
-  for (; t + 3 < nk; t += 2) {                                 // steady state: both steps have two more behind them
-    G256_STEP(t, 0, true);
-    G256_STEP(t + 1, 1, true);
+  if (!half) {
+    for (; t + 3 < nk; t += 2) {                               // steady state: both steps have two more behind them
+      G256_STEP(t, 0, true, 0);
+      G256_STEP(t + 1, 1, true, 0);
+    }
+    if (t < nk) G256_STEP(t, 0, false, 0);                     // the last (up to three) steps: guarded issue, draining waits
+    if (t + 1 < nk) G256_STEP(t + 1, 1, false, 0);
+    if (t + 2 < nk) G256_STEP(t + 2, 0, false, 0);
+  } else {
+    for (; t + 3 < nk; t += 2) {
+      G256_STEP(t, 0, true, 1);
+      G256_STEP(t + 1, 1, true, 1);
+    }
+    if (t < nk) G256_STEP(t, 0, false, 1);
+    if (t + 1 < nk) G256_STEP(t + 1, 1, false, 1);
+    if (t + 2 < nk) G256_STEP(t + 2, 0, false, 1);
   }
-  if (t < nk) G256_STEP(t, 0, false);                          // the last (up to three) steps: guarded issue, draining waits
-  if (t + 1 < nk) G256_STEP(t + 1, 1, false);
-  if (t + 2 < nk) G256_STEP(t + 2, 0, false);
   if (wr == 0) __builtin_amdgcn_s_barrier();                   // pairs with the extra barrier of waves 4–7
+  if (half) {
+    // group 1's K half joins group 0's through LDS (nobody reads tiles any more, every DMA has landed): lane-linear
+    // 16-byte slots, [wave column][accumulator][lane]
+    f32x4* red = reinterpret_cast<f32x4*>(lds) + (wc * 32) * 64 + lane;
+    if (wr == 1) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) red[(m * 4 + n) * 64] = acc[m][n];
+    }
+    __syncthreads();
+    if (wr == 1) return;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] += red[(m * 4 + n) * 64];
+  }
 #undef G256_STAGE_A
 #undef G256_STAGE_B
 #undef G256_RD_A
@@ -350,13 +395,17 @@ void launch_grouped_gemm256(int epilogue, const void* A, int64_t a_stride, const
                             hipStream_t stream) {
   using namespace g256;
   if (max_tiles == 0) return;
+  static const int half_tiles = [] {                                          // DLI_G256_HALF_TILES=0: every tile as a full tile (A/B)
+    const char* v = std::getenv("DLI_G256_HALF_TILES");
+    return (v && v[0] == '0') ? 0 : 1;
+  }();
   const int n_col_blocks = N_out / (epilogue == EPI_SWIGLU ? TN / 2 : TN);
   const int n_virtual = n_col_blocks * k_splits;
   dim3 grid((max_tiles * n_virtual + 7) / 8 * 8);                            // surplus blocks exit on meta[0]
 #define G256_GO(EPI)                                                                                                       \
   hipLaunchKernelGGL((gemm256_kernel<EPI, true>), grid, dim3(512), 0, stream, (const uint16_t*)A, a_stride, (const uint16_t*)W, \
                      w_expert_stride, sorted_ids, tile_expert, meta, topk_w, top_k, out, out_stride, 0, K, N_out, n_col_blocks, \
-                     k_splits, slab_elems, 0, 0)
+                     k_splits, slab_elems, half_tiles, 0)
   if (epilogue == EPI_SWIGLU) G256_GO(EPI_SWIGLU);
   else if (epilogue == EPI_SCATTER) G256_GO(EPI_SCATTER);
   else G256_GO(EPI_SCATTER_SPLITK);

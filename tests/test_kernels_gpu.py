@@ -370,6 +370,39 @@ def test_fused_moe_256_row_tiles_match_reference(T, H, I, E, El, off):
     assert torch.equal(auto, got)
 
 
+@pytest.mark.parametrize("counts,H,I", [([384, 385, 511, 640], 512, 256),            # last tiles of 128 / 129 / 255 / 128 rows
+                                        ([257, 300, 383, 384, 512, 520], 1024, 512),   # 1, 44, 127, 128, 0 (no tail), 8
+                                        ([385, 449, 100], 4096, 1792),                 # Mixtral's shapes; an expert with one half tile only
+                                        ([128, 127, 129], 768, 384)])                  # nothing but last tiles; 12 and 6 K-steps
+def test_fused_moe_256_row_half_tiles_match_reference(counts, H, I):
+    """An expert's last 256-row tile with ≤ 128 routed rows runs as a HALF tile (gemm256.hip: the two wave groups split K
+    over the same 128 rows and add their accumulators through LDS); routing constructed so that both kinds of last tile
+    occur, at the boundary row counts.  Checked against the fp32 reference and against the 128-row tiling."""
+    E = len(counts)
+    left, pairs = list(counts), []
+    while sum(left):
+        a, b = sorted(range(E), key=lambda e: -left[e])[:2]
+        pairs.append((a, b))
+        left[a] -= 1
+        left[b] -= 1
+    assert min(left) == 0 and max(left) == 0
+    T = len(pairs)
+    logits = torch.full((T, E), -4.0, device=DEV)
+    logits.scatter_(1, torch.tensor(pairs, device=DEV), torch.tensor([[3.0, 2.5]], device=DEV).expand(T, 2))
+    logits = logits.bfloat16()
+    assert torch.bincount(torch.topk(logits.float(), 2, -1).indices.flatten(), minlength=E).tolist() == counts
+    x = _bf(T, H, seed=55)
+    w13 = _bf(E, 2 * I, H, seed=56, scale=0.03)
+    w2 = _bf(E, H, I, seed=57, scale=0.03)
+    got = ops.hip().fused_moe(x, logits, w13, w2, 2, 0, 256).float()
+    small = ops.hip().fused_moe(x, logits, w13, w2, 2, 0, 128).float()
+    want = ref.moe_ref(x.float(), logits.float(), w13.float(), w2.float(), 2, 0).float()
+    scale = want.abs().max().clamp_min(1e-6)
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() / scale < 3e-2
+    assert (got - small).abs().max() / scale < 1.5e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 512, 256), (1000, 1024, 4096), (4096, 256, 512), (1, 256, 64), (300, 768, 1024),
                                    (513, 256, 192)])
 def test_dense_gemm256_matches_fp32_reference(M, N, K):
