@@ -336,9 +336,34 @@ __global__ __launch_bounds__(1024) void ep_plan_kernel(const int* __restrict__ i
     for (int d = 0; d <= world; ++d) meta->send_off[d] = off[d];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int d = min(ids[i] / local_experts, world - 1);
-    slot[i] = off[d] + atomicAdd(&fill[d], 1);
+  // slots in the order of the routed-row index (stable, no atomics): the receiving rank's alignment keeps that order, and
+  // which rows share an expert's last GEMM tile must not change between launches (see moe_align_kernel)
+  __shared__ int wcnt[16][kMaxRanks];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (int base = 0; base < n; base += blockDim.x) {
+    if (threadIdx.x < 16 * kMaxRanks) (&wcnt[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = base + threadIdx.x;
+    const int d = i < n ? min(ids[i] / local_experts, world - 1) : -1;
+    int rank = 0;
+    for (int t = 0; t < world; ++t) {
+      const unsigned long long same = __ballot(d == t);
+      if (d == t) rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wave][t] = __popcll(same);
+    }
+    __syncthreads();
+    if (d >= 0) {
+      int before = fill[d];
+      for (int w = 0; w < wave; ++w) before += wcnt[w][d];
+      slot[i] = off[d] + before + rank;
+    }
+    __syncthreads();
+    if (threadIdx.x < world) {
+      int add = 0;
+      for (int w = 0; w < n_waves; ++w) add += wcnt[w][threadIdx.x];
+      fill[threadIdx.x] += add;
+    }
+    __syncthreads();
   }
 }
 

@@ -80,14 +80,44 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__
     meta[1] = off[E_local];
   }
   __syncthreads();
-  const int total = off[E_local];
   for (int i = threadIdx.x; i < capacity_rows; i += blockDim.x) sorted_ids[i] = -1;
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int e = ids[i] - expert_offset;
-    if (e >= 0 && e < E_local) sorted_ids[off[e] + atomicAdd(&pos[e], 1)] = i;
+  // Placement in the order of the routed-row index (stable), without atomics: WHICH rows share an expert's last tile
+  // must not change from launch to launch — a half tile of gemm256.hip adds its K halves in another order than a full
+  // tile, so a row's last bits depend on the tile it lands in, and a step has to replay bit-identically (graph-vs-eager
+  // self-test, greedy reproducibility).  Per chunk of blockDim ids: rank inside the wave by ballots over the experts
+  // present in it, wave totals through LDS, then the running position of the expert.
+  __shared__ int wcnt[16][MOE_MAX_E];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (int base = 0; base < n; base += blockDim.x) {
+    for (int j = threadIdx.x; j < 16 * MOE_MAX_E; j += blockDim.x) (&wcnt[0][0])[j] = 0;
+    __syncthreads();
+    const int i = base + threadIdx.x;
+    int e = i < n ? ids[i] - expert_offset : -1;
+    if (e >= E_local) e = -1;
+    int rank = 0;
+    unsigned long long todo = __ballot(e >= 0);
+    while (todo) {                                          // one round per expert present in this wave
+      const int leader = __ffsll((long long)todo) - 1;
+      const int le = __builtin_amdgcn_readlane(e, leader);
+      const unsigned long long same = __ballot(e == le);
+      if (e == le) rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) wcnt[wave][le] = __popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (e >= 0) {
+      int before = pos[e];
+      for (int w = 0; w < wave; ++w) before += wcnt[w][e];
+      sorted_ids[off[e] + before + rank] = i;
+    }
+    __syncthreads();
+    if (threadIdx.x < E_local) {
+      int add = 0;
+      for (int w = 0; w < n_waves; ++w) add += wcnt[w][threadIdx.x];
+      pos[threadIdx.x] += add;
+    }
+    __syncthreads();
   }
-  (void)total;
 }
 
 // ------------------------------------------------------------------------------------------ grouped GEMM
