@@ -31,11 +31,14 @@
 //     lives in the same lane.
 //   * block → tile mapping: XCD x runs the x-th eighth of the tile order (8-column groups, row tile, column).
 //   * HALF tiles (grouped launches: an expert's last tile with at most 128 routed rows).  The schedule
-//     above stays as it is — same DMAs, same barriers, same counted waits — but the two wave groups share the 128 valid
-//     rows and split K instead of M: group 0 multiplies the first 32 columns of every 64-wide K-step, group 1 the second
-//     32 (half the fragment reads and half the MFMAs per phase for both), and group 1 hands its accumulators to group 0
-//     through the then idle 128 KB of LDS before the epilogue.  The half-tile loop is a second copy of the K loop, chosen
-//     per block from the alignment, so a full tile's instruction stream has no condition in it.
+//     above stays as it is — same DMAs, same barriers, same counted waits — but the wave groups take 64 rows each (group 0
+//     rows 0–63, group 1 rows 64–127: both are the FIRST quadrant pair of the K-step for their group) and the two a1
+//     phases of a K-step keep their DMA issue, waits and barriers but read no A fragments and issue no MFMAs: a K-step is
+//     four MFMA segments instead of eight.  Every output element is summed in the order of a full tile, so a row's bits
+//     do not depend on the kind of tile it lands in.  (First version: both groups on all 128 rows, K split 32 / 32 inside
+//     every phase and an LDS reduce at the end — 0.81 of a full tile, because a phase's reads, waits and barriers do not
+//     halve with its MFMAs; profiles/ab_moe_half_tiles_r3.jsonl.)  The half-tile loop is a second copy of the K loop,
+//     chosen per block from the alignment, so a full tile's instruction stream has no condition in it.
 #include <algorithm>
 #include <cstdlib>
 
@@ -108,13 +111,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   const int e = GROUPED ? tile_expert[tile] : 0;
   const uint16_t* We = W + (int64_t)e * w_expert_stride;
   const int n0 = col_block * (is_swiglu(EPI) ? TN / 2 : TN);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = __builtin_amdgcn_readfirstlane(wave >> 2), wc = wave & 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the LDS-DMA destinations below live in SGPRs
+  const int wr = wave >> 2, wc = wave & 3;
   const int col = lane & 15, g = lane >> 4;
   // at most 128 valid rows: the alignment pads an expert's rows at the END of its last tile
   // (grouped launches carry the switch in lin_begin, which only the dense RANGE mode uses otherwise)
   const bool half = GROUPED && lin_begin != 0 && sorted_ids[tile * TM + TM / 2] < 0;
-  const int wr_a = half ? 0 : wr;                            // wave row whose A rows this wave multiplies
+  const int a_row0 = half ? wr * 64 : wr * 128;              // first A row of this wave's group
 
   // ---- LDS-DMA sources.  A half-tile (a0, a1: 64 rows of each wave row; b0, b1: 32 rows of each wave column) is 128
   // rows = 16 pieces of 8 rows × 128 B = 1 KiB; wave w fills pieces 2w and 2w+1 of every half-tile.  Lane → row
@@ -172,17 +176,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   // fragment reads: A rows wr·128 + m·16 + col, B rows wc·64 + n·16 + col; chunk ks·4 + g of the 64-wide K-step
   // (row offsets that are multiples of 8 rows leave the swizzle term alone: two base addresses per operand — one per
   //  32-wide k half — and compile-time immediates for everything else)
-  const char* a_rd[2] = {lds + lds_off(wr_a * 128 + col, g), lds + lds_off(wr_a * 128 + col, 4 + g)};
+  const char* a_rd[2] = {lds + lds_off(a_row0 + col, g), lds + lds_off(a_row0 + col, 4 + g)};
   const char* b_rd[2] = {lds + STAGE_BYTES + lds_off(wc * 64 + col, g), lds + STAGE_BYTES + lds_off(wc * 64 + col, 4 + g)};
-  // (hm_: the half-tile copy of the loop — a wave touches the k half ks == wr only)
+  // (hm_: the half-tile copy of the loop — no a1 fragments, no a1 MFMAs)
 #define G256_RD_A(dst_, buf_, half_, hm_)                                                                            \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) if (!(hm_) || ks == wr)                                            \
-      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                                  \
-          dst_[m][ks] = *reinterpret_cast<const bf16x8*>(a_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 64 + m * 16) * 128);
-#define G256_RD_B(dst_, buf_, half_, hm_)                                                                            \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) if (!(hm_) || ks == wr)                                            \
-      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                  \
-          dst_[n][ks] = *reinterpret_cast<const bf16x8*>(b_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 32 + n * 16) * 128);
+  if (!((hm_) && (half_) == 1))                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                    \
+        dst_[m][ks] = *reinterpret_cast<const bf16x8*>(a_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 64 + m * 16) * 128);
+#define G256_RD_B(dst_, buf_, half_)                                                                                 \
+  _Pragma("unroll") for (int n = 0; n < 2; ++n) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                      \
+      dst_[n][ks] = *reinterpret_cast<const bf16x8*>(b_rd[ks] + (buf_) * TILE_BYTES + ((half_) * 32 + n * 16) * 128);
   // end of a LOAD segment: my reads are complete before I pass the barrier (→ the half-tile may be re-filled)
 #define G256_END_LOAD()                                                                                              \
   {                                                                                                                  \
@@ -195,11 +198,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   // then the counted DMA wait and the barrier
 #define G256_MMA(fa_, fb_, mh_, nh_, drain_, hm_)                                                                    \
   {                                                                                                                  \
-    __builtin_amdgcn_s_setprio(1);                                                                                   \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) if (!(hm_) || ks == wr)                                          \
-        _Pragma("unroll") for (int m = 0; m < 4; ++m) _Pragma("unroll") for (int n = 0; n < 2; ++n)                   \
-            acc[(mh_) * 4 + m][(nh_) * 2 + n] = mfma16(fb_[n][ks], fa_[m][ks], acc[(mh_) * 4 + m][(nh_) * 2 + n]);    \
-    __builtin_amdgcn_s_setprio(0);                                                                                   \
+    if (!((hm_) && (mh_) == 1)) {                                                                                    \
+      __builtin_amdgcn_s_setprio(1);                                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int m = 0; m < 4; ++m)                  \
+          _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                              \
+              acc[(mh_) * 4 + m][(nh_) * 2 + n] = mfma16(fb_[n][ks], fa_[m][ks], acc[(mh_) * 4 + m][(nh_) * 2 + n]);  \
+      __builtin_amdgcn_s_setprio(0);                                                                                 \
+    }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     if (drain_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                            \
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
     if (more_) G256_STAGE_B((t_) + 2, buf_, f_);                                                                     \
     G256_END_LOAD();                                                                                                 \
     G256_MMA(fa, fb[f_], 0, f_, drain_, hm_);                                                                             \
-    G256_RD_B(fb[o_], buf_, o_, hm_);                                                                                     \
+    G256_RD_B(fb[o_], buf_, o_);                                                                                     \
     if (more_) G256_STAGE_A((t_) + 2, buf_, 0);                                                                      \
     G256_END_LOAD();                                                                                                 \
     G256_MMA(fa, fb[o_], 0, o_, drain_, hm_);                                                                             \
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
     if (more_) G256_STAGE_B((t_) + 2, buf_, o_);                                                                     \
     G256_END_LOAD();                                                                                                 \
     G256_MMA(fa, fb[o_], 1, o_, drain_, hm_);                                                                             \
-    if ((full_) || (t_) + 1 < nk) G256_RD_B(fb[o_], (buf_) ^ 1, o_, hm_);                                                 \
+    if ((full_) || (t_) + 1 < nk) G256_RD_B(fb[o_], (buf_) ^ 1, o_);                                                 \
     if (more_) G256_STAGE_A((t_) + 2, buf_, 1);                                                                      \
     G256_END_LOAD();                                                                                                 \
     G256_MMA(fa, fb[f_], 1, f_, drain_, hm_);                                                                             \
@@ -254,11 +259,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (half) {
-    G256_RD_B(fb[0], 0, 0, 1);
-  } else {
-    G256_RD_B(fb[0], 0, 0, 0);
-  }
+  G256_RD_B(fb[0], 0, 0);
   if (wr == 1) {                                               // the stagger: waves 4–7 run one segment behind
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -284,23 +285,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
     if (t + 2 < nk) G256_STEP(t + 2, 0, false, 1);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();                   // pairs with the extra barrier of waves 4–7
-  if (half) {
-    // group 1's K half joins group 0's through LDS (nobody reads tiles any more, every DMA has landed): lane-linear
-    // 16-byte slots, [wave column][accumulator][lane]
-    f32x4* red = reinterpret_cast<f32x4*>(lds) + (wc * 32) * 64 + lane;
-    if (wr == 1) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) red[(m * 4 + n) * 64] = acc[m][n];
-    }
-    __syncthreads();
-    if (wr == 1) return;
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] += red[(m * 4 + n) * 64];
-  }
 #undef G256_STAGE_A
 #undef G256_STAGE_B
 #undef G256_RD_A
@@ -325,7 +309,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(
   }
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    const int lrow = wr * 128 + m * 16 + col;
+    if (half && m >= 4) break;                                 // a half tile has no a1 rows
+    const int lrow = a_row0 + m * 16 + col;
     const int prow = tile * TM + lrow;
     const int sid = GROUPED ? sorted_ids[prow] : (prow < M ? prow : -1);
     const int64_t srow = (ranged && (EPI == EPI_PLAIN_SPLITK || EPI == EPI_SWIGLU_SPLITK)) ? lrow : prow;
