@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     v_scale = kv_scales[Hkv + kvh];
   }
   const int G = Hq / Hkv;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: page loop, block-table reads and page bases in SGPRs
   const int col = lane & 15, g = lane >> 4;
   const int L = seq_lens[seq];
   const int nblk = (L + 31) >> 5;
@@ -404,7 +405,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_kernel(
   if ((int)(blockIdx.x >> 3) >= per_xcd || lin >= total) return;
   const int kvh = lin / num_tiles;
   const int G = Hq / Hkv;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations and the wave's page bounds in SGPRs
   const int c32 = lane & 31, hi = lane >> 5;
   const int tile_id = num_tiles - 1 - (lin - kvh * num_tiles);
   if (KV8 && kv_scales != nullptr) {

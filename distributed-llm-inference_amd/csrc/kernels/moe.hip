@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void grouped_gemm_kernel(
   const int e = tile_expert[tile];
   const uint16_t* We = W + (int64_t)e * w_expert_stride;
   const int n0 = col_block * (EPI == EPI_SWIGLU ? BN / 2 : BN);   // SWIGLU: 64 output columns per tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int col = lane & 15, g = lane >> 4;
 
