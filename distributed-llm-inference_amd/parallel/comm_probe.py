@@ -152,6 +152,17 @@ def main(argv=None) -> int:
     return 0
 
 
+def child_env(env: dict) -> dict:
+    """Environment of the probe child: the probe builds its OWN rendezvous (tcp://127.0.0.1:port, rank 0 hosts the store), so
+    nothing of the launcher's may leak in.  Under ``torch.distributed.run`` the workers carry ``TORCHELASTIC_USE_AGENT_STORE``:
+    with it set, ``init_process_group`` makes EVERY rank a client of a store it expects the agent to host at that address —
+    nobody listens on the probe's port and the child sits in the connect until the probe's time-out (found with the driver's
+    invocation, 2 ranks: 150 s lost and RCCL + the custom collectives declared unusable)."""
+    drop = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "LOCAL_WORLD_SIZE",
+            "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")
+    return {k: v for k, v in env.items() if k not in drop and not k.startswith("TORCHELASTIC_")}
+
+
 def probe_in_subprocess(rank: int, world: int, device: int, port: int, share_gpu: bool = False, seconds: float = 5.0,
                         timeout: float = 150.0, full: bool = False, iters: int = 10, max_bytes: int = 64 << 20) -> dict:
     """Run the probe for this rank in a child process; never raises.  On a crash, a time-out or a missing result the
@@ -165,9 +176,7 @@ def probe_in_subprocess(rank: int, world: int, device: int, port: int, share_gpu
         cmd.append("--share-gpu")
     if full:
         cmd.append("--full")
-    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
-        env.pop(k, None)                                     # the probe builds its own rendezvous
+    env = child_env(dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", "")))
     fail = {"world": world, "rank": rank, "device": device, "rccl_ok": False, "custom_ar_ok": False, "rccl_ranks_joined": 0,
             "all_reduce_table": []}
     t0 = time.perf_counter()

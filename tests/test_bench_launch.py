@@ -186,3 +186,32 @@ def test_emulated_rank_holds_exactly_rank_zero_shards():
     x = torch.randn(4, cfg.hidden_size)
     assert emu.ctx.all_reduce(x) is not x and torch.equal(emu.ctx.all_reduce(x), x)
     assert emu.ctx.all_gather_last_dim(torch.ones(3, 5)).shape == (3, 40) and not emu.ctx.distributed
+
+
+def test_probe_child_environment_drops_the_launcher_rendezvous():
+    """Under `torch.distributed.run` every worker carries TORCHELASTIC_USE_AGENT_STORE: with it, a tcp:// rendezvous makes
+    ALL ranks clients of a store nobody hosts.  The comm probe's children build their own rendezvous, so their environment
+    must not carry it (the GPU rehearsal of the driver's 2-rank invocation lost 150 s in that connect and declared RCCL
+    and the custom collectives unusable).  Two children with the scrubbed environment rendezvous and all-reduce."""
+    from dli_amd.parallel.comm_probe import child_env
+    from dli_amd.runtime.launch import free_port
+    dirty = dict(os.environ, TORCHELASTIC_USE_AGENT_STORE="True", TORCHELASTIC_RESTART_COUNT="0", TORCHELASTIC_RUN_ID="x",
+                 RANK="5", WORLD_SIZE="9", LOCAL_RANK="5", GROUP_RANK="0", MASTER_PORT="1", LOCAL_WORLD_SIZE="9")
+    env = child_env(dirty)
+    assert not [k for k in env if k.startswith("TORCHELASTIC_")]
+    assert not {"RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE"} & set(env)
+    assert env["PATH"] == os.environ["PATH"]
+    port = free_port()
+    code = ("import sys, datetime, torch, torch.distributed as dist\n"
+            "r = int(sys.argv[1])\n"
+            f"dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{port}', rank=r, world_size=2, "
+            "timeout=datetime.timedelta(seconds=60))\n"
+            "x = torch.ones(4) * (r + 1)\n"
+            "dist.all_reduce(x)\n"
+            "assert float(x[0]) == 3.0\n"
+            "dist.destroy_process_group()\n")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out[-2000:]
