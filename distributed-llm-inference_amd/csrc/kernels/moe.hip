@@ -86,37 +86,48 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__
   // tile, so a row's last bits depend on the tile it lands in, and a step has to replay bit-identically (graph-vs-eager
   // self-test, greedy reproducibility).  Per chunk of blockDim ids: rank inside the wave by ballots over the experts
   // present in it, wave totals through LDS, then the running position of the expert.
-  __shared__ int wcnt[16][MOE_MAX_E];
+  // One barrier per chunk: the per-wave counts and the running positions are double-buffered by the chunk's parity.
+  __shared__ int wcnt[2][16][MOE_MAX_E], run[2][MOE_MAX_E];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  for (int base = 0; base < n; base += blockDim.x) {
-    for (int j = threadIdx.x; j < 16 * MOE_MAX_E; j += blockDim.x) (&wcnt[0][0])[j] = 0;
-    __syncthreads();
+  if (threadIdx.x < MOE_MAX_E) run[0][threadIdx.x] = 0;
+  const bool few = E_local <= 16;                          // few experts: one ballot per expert, every wave writes every count
+  __syncthreads();
+  int par = 0;
+  for (int base = 0; base < n; base += blockDim.x, par ^= 1) {
     const int i = base + threadIdx.x;
     int e = i < n ? ids[i] - expert_offset : -1;
     if (e >= E_local) e = -1;
     int rank = 0;
-    unsigned long long todo = __ballot(e >= 0);
-    while (todo) {                                          // one round per expert present in this wave
-      const int leader = __ffsll((long long)todo) - 1;
-      const int le = __builtin_amdgcn_readlane(e, leader);
-      const unsigned long long same = __ballot(e == le);
-      if (e == le) rank = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) wcnt[wave][le] = __popcll(same);
-      todo &= ~same;
+    if (few) {
+      for (int t = 0; t < E_local; ++t) {
+        const unsigned long long same = __ballot(e == t);
+        if (e == t) rank = __popcll(same & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[par][wave][t] = __popcll(same);
+      }
+    } else {
+      static_assert(MOE_MAX_E <= 64, "one lane per expert clears the wave's row");
+      if (lane < MOE_MAX_E) wcnt[par][wave][lane] = 0;      // this wave's own row: same-wave LDS order, no barrier needed
+      unsigned long long todo = __ballot(e >= 0);
+      while (todo) {                                        // one round per expert present in this wave
+        const int leader = __ffsll((long long)todo) - 1;
+        const int le = __builtin_amdgcn_readlane(e, leader);
+        const unsigned long long same = __ballot(e == le);
+        if (e == le) rank = __popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) wcnt[par][wave][le] = __popcll(same);
+        todo &= ~same;
+      }
     }
     __syncthreads();
     if (e >= 0) {
-      int before = pos[e];
-      for (int w = 0; w < wave; ++w) before += wcnt[w][e];
+      int before = run[par][e];
+      for (int w = 0; w < wave; ++w) before += wcnt[par][w][e];
       sorted_ids[off[e] + before + rank] = i;
     }
-    __syncthreads();
-    if (threadIdx.x < E_local) {
-      int add = 0;
-      for (int w = 0; w < n_waves; ++w) add += wcnt[w][threadIdx.x];
-      pos[threadIdx.x] += add;
+    if (threadIdx.x < E_local) {                            // positions for the next chunk, read after ITS barrier
+      int add = run[par][threadIdx.x];
+      for (int w = 0; w < n_waves; ++w) add += wcnt[par][w][threadIdx.x];
+      run[par ^ 1][threadIdx.x] = add;
     }
-    __syncthreads();
   }
 }
 
