@@ -270,8 +270,13 @@ def drain_collectives() -> None:
             is_rccl = "nccl" in str(dist.get_backend(pg))
         except Exception:
             continue
-        if is_rccl and hasattr(pg, "_wait_for_pending_works"):
+        if not is_rccl:
+            continue
+        if hasattr(pg, "_wait_for_pending_works"):
             pg._wait_for_pending_works()
+        else:                                                # older torch: out-wait the watchdog's poll interval instead
+            import time
+            time.sleep(0.3)
 
 
 def make_tp_context(tp_size: int, ep_size: int = 1, ranks: Optional[list] = None, with_cpu_group: bool = True,
