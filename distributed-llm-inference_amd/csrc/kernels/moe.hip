@@ -81,11 +81,12 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const int* __restrict__
   }
   __syncthreads();
   for (int i = threadIdx.x; i < capacity_rows; i += blockDim.x) sorted_ids[i] = -1;
-  // Placement in the order of the routed-row index (stable), without atomics: WHICH rows share an expert's last tile
-  // must not change from launch to launch — a half tile of gemm256.hip adds its K halves in another order than a full
-  // tile, so a row's last bits depend on the tile it lands in, and a step has to replay bit-identically (graph-vs-eager
-  // self-test, greedy reproducibility).  Per chunk of blockDim ids: rank inside the wave by ballots over the experts
-  // present in it, wave totals through LDS, then the running position of the expert.
+  // Placement in the order of the routed-row index (stable), without atomics: every launch produces the same sorted_ids,
+  // so WHICH rows share an expert's last tile never changes from launch to launch and a step replays bit-identically
+  // whatever the tile variants do with a partly filled tile (graph-vs-eager self-test, greedy reproducibility; the
+  // first half-tile version of gemm256.hip summed K in another order than a full tile and exposed the atomics' order).
+  // Per chunk of blockDim ids: rank inside the wave by ballots over the experts present in it, wave totals through
+  // LDS, then the running position of the expert.
   // One barrier per chunk: the per-wave counts and the running positions are double-buffered by the chunk's parity.
   __shared__ int wcnt[2][16][MOE_MAX_E], run[2][MOE_MAX_E];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;

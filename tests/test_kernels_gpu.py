@@ -375,8 +375,8 @@ def test_fused_moe_256_row_tiles_match_reference(T, H, I, E, El, off):
                                         ([385, 449, 100], 4096, 1792),                 # Mixtral's shapes; an expert with one half tile only
                                         ([128, 127, 129], 768, 384)])                  # nothing but last tiles; 12 and 6 K-steps
 def test_fused_moe_256_row_half_tiles_match_reference(counts, H, I):
-    """An expert's last 256-row tile with ≤ 128 routed rows runs as a HALF tile (gemm256.hip: the two wave groups split K
-    over the same 128 rows and add their accumulators through LDS); routing constructed so that both kinds of last tile
+    """An expert's last 256-row tile with ≤ 128 routed rows runs as a HALF tile (gemm256.hip: the wave groups take 64 rows
+    each and the a1 phases of the K-step run empty); routing constructed so that both kinds of last tile
     occur, at the boundary row counts.  Checked against the fp32 reference and against the 128-row tiling."""
     E = len(counts)
     left, pairs = list(counts), []
@@ -401,8 +401,8 @@ def test_fused_moe_256_row_half_tiles_match_reference(counts, H, I):
     assert torch.isfinite(got).all()
     assert (got - want).abs().max() / scale < 3e-2
     assert (got - small).abs().max() / scale < 1.5e-2
-    # a half tile adds its K halves in another order than a full tile, so a row's last bits depend on the tile it lands
-    # in: the alignment places rows in index order (no atomics) and every launch must give the same bits
+    # the alignment places rows in index order (no atomics) and a half tile sums in a full tile's order: every launch
+    # must give the same bits (the first half-tile version split K between the wave groups and did not)
     for _ in range(6):
         assert torch.equal(ops.hip().fused_moe(x, logits, w13, w2, 2, 0, 256).float(), got)
 
